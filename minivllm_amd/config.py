@@ -1,0 +1,214 @@
+"""Typed configuration for the engine and the model.
+
+The reference passes one flat ``dict`` from ``main.py`` to ``LLMEngine`` and
+``ModelRunner`` with no validation (reference: main.py:15-41,
+src/myvllm/engine/llm_engine.py:14-22, src/myvllm/engine/model_runner.py:17-43).
+Here the same keys (including the duplicate spellings the reference uses,
+``max_num_batched_tokens``/``max_num_batch_tokens`` and
+``max_num_sequences``/``max_num_seqs``) are parsed once into two dataclasses so
+that every component reads ONE value for ``block_size`` and friends.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field, fields, asdict
+from typing import Any, Dict, Optional
+
+import torch
+
+
+_DTYPES = {
+    "bf16": torch.bfloat16, "bfloat16": torch.bfloat16,
+    "fp16": torch.float16, "float16": torch.float16, "half": torch.float16,
+    "fp32": torch.float32, "float32": torch.float32, "float": torch.float32,
+}
+
+
+def parse_dtype(x) -> torch.dtype:
+    if isinstance(x, torch.dtype):
+        return x
+    try:
+        return _DTYPES[str(x).lower()]
+    except KeyError:
+        raise ValueError(f"unknown dtype {x!r}; expected one of {sorted(_DTYPES)}")
+
+
+@dataclass
+class ModelConfig:
+    """Qwen3 architecture hyper-parameters (reference keys: model_runner.py:28-43)."""
+    vocab_size: int = 151936
+    hidden_size: int = 1024
+    num_heads: int = 16
+    num_kv_heads: int = 8
+    head_dim: int = 128
+    intermediate_size: int = 3072
+    num_layers: int = 28
+    rms_norm_epsilon: float = 1e-6
+    qkv_bias: bool = False
+    ffn_bias: bool = False
+    base: float = 1_000_000.0          # RoPE theta
+    max_position: int = 40960
+    scale: float = 1.0                 # extra multiplier on 1/sqrt(head_dim)
+    tie_word_embeddings: bool = True
+    name: str = "qwen3-custom"
+
+    def num_parameters(self) -> int:
+        h, i, v = self.hidden_size, self.intermediate_size, self.vocab_size
+        qkv = h * (self.num_heads + 2 * self.num_kv_heads) * self.head_dim
+        o = self.num_heads * self.head_dim * h
+        mlp = 3 * h * i
+        per_layer = qkv + o + mlp + 2 * h + 2 * self.head_dim
+        emb = v * h * (1 if self.tie_word_embeddings else 2)
+        return per_layer * self.num_layers + emb + h
+
+    def kv_bytes_per_token(self, dtype: torch.dtype, tp: int = 1) -> int:
+        itemsize = torch.empty((), dtype=dtype).element_size()
+        return 2 * self.num_layers * (self.num_kv_heads // tp) * self.head_dim * itemsize
+
+
+# Public Qwen3 shapes.  head_dim is 128 for every size (not hidden/num_heads).
+QWEN3_PRESETS: Dict[str, Dict[str, Any]] = {
+    "qwen3-0.6b": dict(hidden_size=1024, num_layers=28, num_heads=16, num_kv_heads=8, head_dim=128,
+                       intermediate_size=3072, vocab_size=151936, tie_word_embeddings=True),
+    "qwen3-1.7b": dict(hidden_size=2048, num_layers=28, num_heads=16, num_kv_heads=8, head_dim=128,
+                       intermediate_size=6144, vocab_size=151936, tie_word_embeddings=True),
+    "qwen3-4b": dict(hidden_size=2560, num_layers=36, num_heads=32, num_kv_heads=8, head_dim=128,
+                     intermediate_size=9728, vocab_size=151936, tie_word_embeddings=True),
+    "qwen3-8b": dict(hidden_size=4096, num_layers=36, num_heads=32, num_kv_heads=8, head_dim=128,
+                     intermediate_size=12288, vocab_size=151936, tie_word_embeddings=False),
+    "qwen3-14b": dict(hidden_size=5120, num_layers=40, num_heads=40, num_kv_heads=8, head_dim=128,
+                      intermediate_size=17408, vocab_size=151936, tie_word_embeddings=False),
+    "qwen3-32b": dict(hidden_size=5120, num_layers=64, num_heads=64, num_kv_heads=8, head_dim=128,
+                      intermediate_size=25600, vocab_size=151936, tie_word_embeddings=False),
+    # tiny shapes for tests / smoke runs
+    "qwen3-tiny": dict(hidden_size=128, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64,
+                       intermediate_size=256, vocab_size=512, tie_word_embeddings=True,
+                       max_position=512),
+}
+
+
+def model_preset(name: str, **overrides) -> ModelConfig:
+    key = name.lower()
+    if key not in QWEN3_PRESETS:
+        raise KeyError(f"unknown model preset {name!r}; have {sorted(QWEN3_PRESETS)}")
+    kw = dict(QWEN3_PRESETS[key])
+    kw.update(overrides)
+    return ModelConfig(name=key, **kw)
+
+
+_MODEL_KEYS = {f.name for f in fields(ModelConfig)}
+
+
+@dataclass
+class EngineConfig:
+    """Everything the engine, scheduler and runner need (reference keys: SURVEY of main.py:15-41)."""
+    model: ModelConfig = field(default_factory=ModelConfig)
+    # scheduler budgets
+    max_num_sequences: int = 256
+    max_num_batched_tokens: int = 16384
+    block_size: int = 256
+    # None => derive the number of KV blocks from free device memory (the
+    # reference keeps a separate, unrelated 'max_cached_blocks': llm_engine.py:18)
+    max_cached_blocks: Optional[int] = None
+    eos: int = 151645
+    # runtime
+    world_size: int = 1
+    enforce_eager: bool = False
+    max_model_length: int = 4096
+    gpu_memory_utilization: float = 0.9
+    model_name_or_path: Optional[str] = None
+    dtype: torch.dtype = torch.bfloat16
+    device: str = "auto"               # 'auto' | 'cuda' | 'cpu'
+    seed: int = 0
+    # distributed rendezvous (the reference hard-codes tcp://localhost:12345, model_runner.py:24)
+    master_addr: str = "127.0.0.1"
+    master_port: int = 29512
+    dist_backend: str = "auto"         # 'auto' | 'nccl' | 'gloo'
+    # decode graphs
+    graph_batch_sizes: Optional[list] = None
+    log_stats: bool = False
+    checkpoint_path: Optional[str] = None
+
+    # --- derived ---------------------------------------------------------
+    def resolved_device(self) -> str:
+        if self.device == "auto":
+            return "cuda" if torch.cuda.is_available() else "cpu"
+        return self.device
+
+    def validate(self) -> "EngineConfig":
+        m = self.model
+        if self.block_size <= 0 or (self.block_size & (self.block_size - 1)):
+            raise ValueError(f"block_size must be a power of two, got {self.block_size}")
+        if m.num_heads % m.num_kv_heads:
+            raise ValueError("num_heads must be a multiple of num_kv_heads")
+        if m.num_heads % self.world_size or m.num_kv_heads % self.world_size:
+            raise ValueError(
+                f"world_size={self.world_size} must divide num_heads={m.num_heads} and "
+                f"num_kv_heads={m.num_kv_heads} (KV-head replication is not supported)")
+        if m.intermediate_size % self.world_size:
+            raise ValueError("world_size must divide intermediate_size")
+        if m.head_dim not in (64, 128) and self.resolved_device() == "cuda":
+            raise ValueError("HIP attention kernels support head_dim 64 and 128")
+        if self.max_model_length > m.max_position:
+            raise ValueError(
+                f"max_model_length={self.max_model_length} exceeds the RoPE table "
+                f"max_position={m.max_position}")
+        if self.max_num_batched_tokens < 1 or self.max_num_sequences < 1:
+            raise ValueError("scheduler budgets must be positive")
+        if not (0.0 < self.gpu_memory_utilization <= 1.0):
+            raise ValueError("gpu_memory_utilization must be in (0, 1]")
+        return self
+
+    @property
+    def max_blocks_per_seq(self) -> int:
+        return (self.max_model_length + self.block_size - 1) // self.block_size
+
+    def to_dict(self) -> Dict[str, Any]:
+        d = asdict(self)
+        d["dtype"] = str(self.dtype).replace("torch.", "")
+        return d
+
+    # --- construction ----------------------------------------------------
+    @classmethod
+    def from_dict(cls, cfg: Dict[str, Any]) -> "EngineConfig":
+        """Accept the reference's flat dict (main.py:15-41) or a nested one.
+
+        Unknown keys raise, so typos do not silently fall back to defaults.
+        """
+        cfg = dict(cfg)
+        if isinstance(cfg.get("model"), ModelConfig):
+            model = cfg.pop("model")
+        else:
+            preset = cfg.pop("model_preset", None)
+            mkw = {k: cfg.pop(k) for k in list(cfg) if k in _MODEL_KEYS}
+            if isinstance(cfg.get("model"), dict):
+                mkw.update(cfg.pop("model"))
+            model = model_preset(preset, **mkw) if preset else ModelConfig(**mkw)
+        # duplicate spellings used by the reference
+        if "max_num_seqs" in cfg:
+            v = cfg.pop("max_num_seqs")
+            cfg.setdefault("max_num_sequences", v)
+        if "max_num_batch_tokens" in cfg:
+            v = cfg.pop("max_num_batch_tokens")
+            # the reference uses this one only for the warm-up shape; the
+            # scheduler budget key wins when both are present
+            cfg.setdefault("max_num_batched_tokens", v)
+        if "dtype" in cfg:
+            cfg["dtype"] = parse_dtype(cfg["dtype"])
+        known = {f.name for f in fields(cls)}
+        unknown = set(cfg) - known
+        if unknown:
+            raise KeyError(f"unknown config keys: {sorted(unknown)}")
+        out = cls(model=model, **cfg)
+        # the reference demo sets max_position == max_model_length == 128; keep
+        # whatever the user gave but make the pair consistent
+        if out.max_model_length > out.model.max_position:
+            out.max_model_length = out.model.max_position
+        return out.validate()
+
+
+def as_engine_config(cfg) -> EngineConfig:
+    if isinstance(cfg, EngineConfig):
+        return cfg.validate()
+    if isinstance(cfg, dict):
+        return EngineConfig.from_dict(cfg)
+    raise TypeError(f"config must be a dict or EngineConfig, got {type(cfg)}")

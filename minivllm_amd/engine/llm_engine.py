@@ -1,0 +1,171 @@
+"""Engine façade: tokenizer + scheduler + model runner(s).
+
+API follows the reference's ``LLMEngine`` (reference: src/myvllm/engine/llm_engine.py:13-88):
+``LLMEngine(config: dict)``, ``add_prompt``, ``step() -> (finished, num_tokens, is_prefill)``,
+``generate(prompts, sampling_params) -> {'text': [...], 'token_ids': [...]}``, ``exit``.
+
+Differences: the runner is built first and the scheduler's KV block count is the number the
+runner really allocated (the reference trusts an unrelated ``max_cached_blocks``); ``step``
+always returns a 3-tuple; prompts may be strings or token-id lists; throughput is
+aggregated per phase (prefill tok/s, decode tok/s) over the whole run in ``self.stats``
+besides the per-step print; worker processes are checked for liveness each step; and when the
+process was started by ``torchrun`` (RANK/WORLD_SIZE set) no workers are spawned — the other
+ranks are expected to call ``run_worker``.
+"""
+from __future__ import annotations
+
+import atexit
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence as Seq, Tuple, Union
+
+import torch.multiprocessing as mp
+
+from minivllm_amd.config import EngineConfig, as_engine_config
+from minivllm_amd.engine.model_runner import ModelRunner
+from minivllm_amd.engine.scheduler import Scheduler
+from minivllm_amd.engine.sequence import Sequence
+from minivllm_amd.parallel.group import env_rank_world
+from minivllm_amd.sampling_parameters import SamplingParams
+from minivllm_amd.utils.tokenizer import load_tokenizer
+
+
+@dataclass
+class EngineStats:
+    prefill_tokens: int = 0
+    prefill_time: float = 0.0
+    prefill_steps: int = 0
+    decode_tokens: int = 0
+    decode_time: float = 0.0
+    decode_steps: int = 0
+
+    @property
+    def prefill_tok_s(self) -> float:
+        return self.prefill_tokens / self.prefill_time if self.prefill_time else 0.0
+
+    @property
+    def decode_tok_s(self) -> float:
+        return self.decode_tokens / self.decode_time if self.decode_time else 0.0
+
+    def as_dict(self) -> dict:
+        return dict(prefill_tokens=self.prefill_tokens, prefill_steps=self.prefill_steps,
+                    prefill_tok_s=self.prefill_tok_s, decode_tokens=self.decode_tokens,
+                    decode_steps=self.decode_steps, decode_tok_s=self.decode_tok_s)
+
+
+def _worker_main(config: EngineConfig, rank: int) -> None:
+    ModelRunner(config, rank)            # enters loop() and returns after 'exit'
+
+
+def run_worker(config, rank: int) -> None:
+    """Entry point for a non-zero rank launched independently (e.g. by torchrun)."""
+    ModelRunner(as_engine_config(config), rank)
+
+
+class LLMEngine:
+    def __init__(self, config: Union[dict, EngineConfig], spawn_workers: Optional[bool] = None):
+        self.cfg = as_engine_config(config)
+        cfg = self.cfg
+        self.workers: List[mp.Process] = []
+        env_rank, _, env_world = env_rank_world()
+        if spawn_workers is None:
+            spawn_workers = not (env_world == cfg.world_size and cfg.world_size > 1)
+        if cfg.world_size > 1 and spawn_workers:
+            ctx = mp.get_context("spawn")
+            for r in range(1, cfg.world_size):
+                p = ctx.Process(target=_worker_main, args=(cfg, r), daemon=True)
+                p.start()
+                self.workers.append(p)
+        self.model_runner = ModelRunner(cfg, 0)
+        self.scheduler = Scheduler(cfg.max_num_sequences, cfg.max_num_batched_tokens,
+                                   self.model_runner.num_kv_blocks, cfg.block_size, cfg.eos,
+                                   max_model_length=cfg.max_model_length)
+        self.tokenizer = load_tokenizer(cfg.model_name_or_path, cfg.model.vocab_size)
+        self.stats = EngineStats()
+        self._exited = False
+        atexit.register(self.exit)
+
+    # ------------------------------------------------------------ lifecycle
+    def exit(self) -> None:
+        if self._exited:
+            return
+        self._exited = True
+        try:
+            self.model_runner.call("exit")
+        finally:
+            for p in self.workers:
+                p.join(timeout=30)
+                if p.is_alive():
+                    p.terminate()
+
+    def _check_workers(self) -> None:
+        for p in self.workers:
+            if not p.is_alive():
+                raise RuntimeError(f"tensor-parallel worker pid={p.pid} died "
+                                   f"(exit code {p.exitcode})")
+
+    # --------------------------------------------------------------- requests
+    def add_prompt(self, prompt: Union[str, Seq[int]],
+                   sampling_params: Optional[SamplingParams] = None) -> Sequence:
+        if isinstance(prompt, str):
+            token_ids = self.tokenizer.encode(prompt)
+        else:
+            token_ids = list(prompt)
+        vocab = self.cfg.model.vocab_size
+        if any(t < 0 or t >= vocab for t in token_ids):
+            raise ValueError(f"prompt token id outside the model vocabulary [0, {vocab})")
+        seq = Sequence(token_ids, sampling_params, block_size=self.cfg.block_size)
+        self.scheduler.add_sequence(seq)
+        return seq
+
+    def step(self) -> Tuple[List[Tuple[int, List[int]]], int, bool]:
+        """One engine iteration.  Returns (finished [(seq_id, completion ids)],
+        tokens processed, is_prefill).  Tokens processed = newly computed prompt tokens
+        for a prefill step, number of sequences for a decode step
+        (reference: llm_engine.py:48-60)."""
+        seqs, is_prefill = self.scheduler.schedule()
+        if not seqs:
+            if not self.scheduler.is_finished():
+                raise RuntimeError("scheduler made no progress: KV cache too small for the "
+                                   "oldest waiting request")
+            return [], 0, False
+        self._check_workers()
+        if is_prefill:
+            num_tokens = sum(len(s) - s.num_cached_tokens for s in seqs)
+        else:
+            num_tokens = len(seqs)
+        token_ids = self.model_runner.run(seqs, is_prefill)
+        finished = self.scheduler.postprocess(seqs, token_ids)
+        return ([(s.seq_id, s.completion_token_ids) for s in finished], num_tokens, is_prefill)
+
+    def is_finished(self) -> bool:
+        return self.scheduler.is_finished()
+
+    def generate(self, prompts: Seq[Union[str, Seq[int]]],
+                 sampling_params: Union[SamplingParams, Seq[SamplingParams], None] = None,
+                 verbose: Optional[bool] = None) -> Dict[str, list]:
+        verbose = self.cfg.log_stats if verbose is None else verbose
+        if sampling_params is None or isinstance(sampling_params, SamplingParams):
+            sampling_params = [sampling_params] * len(prompts)
+        order = [self.add_prompt(p, sp).seq_id for p, sp in zip(prompts, sampling_params)]
+        done: Dict[int, List[int]] = {}
+        st = self.stats
+        while not self.scheduler.is_finished():
+            t0 = time.perf_counter()
+            finished, num_tokens, is_prefill = self.step()
+            dt = time.perf_counter() - t0
+            if is_prefill:
+                st.prefill_tokens += num_tokens
+                st.prefill_time += dt
+                st.prefill_steps += 1
+            else:
+                st.decode_tokens += num_tokens
+                st.decode_time += dt
+                st.decode_steps += 1
+            if verbose:
+                phase = "prefilling" if is_prefill else "decoding"
+                print(f"{num_tokens / dt:.1f} tokens/sec during {phase} "
+                      f"({num_tokens} tokens, {dt * 1e3:.2f} ms)")
+            done.update(finished)
+        token_ids = [done[i] for i in order]
+        return {"text": [self.tokenizer.decode(t) for t in token_ids], "token_ids": token_ids}

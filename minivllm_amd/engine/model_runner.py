@@ -1,0 +1,513 @@
+"""Per-rank model executor: owns the model shard, the paged KV cache, batch preparation,
+hipGraph-captured decode steps and the worker side of the control channel.
+
+Responsibilities mirror the reference's ``ModelRunner`` (reference:
+src/myvllm/engine/model_runner.py:13-369): build the model, warm up, size and allocate the
+KV cache from free device memory, turn scheduled sequences into flat tensors
+(``prepare_prefill`` / ``prepare_decode``), run the model (eager or graph replay), sample
+on rank 0, and serve ``call(method, *args)`` requests from rank 0 on worker ranks.
+
+MI355X-first differences:
+* the batch is prepared ONCE on rank 0 with vectorised numpy and shipped to workers as raw
+  int32 arrays (no pickled ``Sequence`` objects, no per-token Python loops);
+* every step uploads one pinned staging buffer with a single H2D copy; rotary positions are
+  part of it (the reference recomputes them in every layer with a host sync);
+* the KV cache is one allocation sized from ``hipMemGetInfo`` x utilisation and its block
+  count is what the scheduler is built from; blocks are stored head-major so a (block,
+  kv-head) pair is one contiguous slab;
+* decode graphs contain the whole step including LM head and sampler, and the graph's
+  inputs live at fixed offsets of one static device buffer;
+* with tensor parallelism each rank samples on its vocabulary shard and only
+  (value, index) pairs are exchanged.
+"""
+from __future__ import annotations
+
+import os
+import time
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence as Seq
+
+import numpy as np
+import torch
+
+from minivllm_amd.config import EngineConfig, as_engine_config
+from minivllm_amd.engine.rpc import ShmBroadcastChannel
+from minivllm_amd.engine.sequence import Sequence
+from minivllm_amd.layers.sampler import SamplerLayer
+from minivllm_amd.models.qwen3 import Qwen3ForCausalLM
+from minivllm_amd.parallel import group as pg
+from minivllm_amd.utils.context import reset_context, set_context
+
+
+@dataclass
+class Batch:
+    """Host-side description of one engine step (what crosses the control channel)."""
+    is_prefill: bool
+    num_seqs: int
+    num_tokens: int
+    max_seqlen_q: int = 0
+    max_seqlen_k: int = 0
+    max_context_len: int = 0
+    has_prefix: bool = False
+    step: int = 0
+    arrays: Dict[str, np.ndarray] = field(default_factory=dict)
+
+    def scalars(self) -> dict:
+        return dict(is_prefill=self.is_prefill, num_seqs=self.num_seqs, num_tokens=self.num_tokens,
+                    max_seqlen_q=self.max_seqlen_q, max_seqlen_k=self.max_seqlen_k,
+                    max_context_len=self.max_context_len, has_prefix=self.has_prefix,
+                    step=self.step)
+
+
+def default_graph_batch_sizes(max_bs: int) -> List[int]:
+    """Same bucket policy as the reference: 1,2,4,8 then multiples of 16
+    (reference: model_runner.py:334)."""
+    sizes = [b for b in (1, 2, 4, 8) if b <= max_bs] + list(range(16, max_bs + 1, 16))
+    if max_bs not in sizes:
+        sizes.append(max_bs)
+    return sorted(set(sizes))
+
+
+class ModelRunner:
+    def __init__(self, config, rank: int = 0, event=None, spawn_loop: bool = True):
+        """``event`` is accepted for signature compatibility with the reference and unused:
+        the control channel is addressed by name.  A worker rank (rank > 0) enters
+        ``loop()`` at the end of construction when ``spawn_loop`` is set."""
+        self.cfg: EngineConfig = as_engine_config(config)
+        cfg = self.cfg
+        self.rank = rank
+        self.world_size = cfg.world_size
+        self.block_size = cfg.block_size
+        self.enforce_eager = cfg.enforce_eager
+        dev_type = cfg.resolved_device()
+        if dev_type == "cuda":
+            local = int(os.environ.get("LOCAL_RANK", rank)) if "LOCAL_RANK" in os.environ else rank
+            self.device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
+            torch.cuda.set_device(self.device)
+        else:
+            self.device = torch.device("cpu")
+        self.on_gpu = self.device.type == "cuda"
+        self.dtype = cfg.dtype if self.on_gpu else (cfg.dtype if cfg.dtype != torch.float16
+                                                    else torch.float32)
+
+        pg.init_tensor_parallel(rank, cfg.world_size, cfg.dist_backend, cfg.master_addr,
+                                cfg.master_port, self.device)
+
+        # ---- model shard -------------------------------------------------
+        prev = torch.get_default_dtype()
+        torch.set_default_dtype(self.dtype)
+        try:
+            with torch.device(self.device):
+                self.model = Qwen3ForCausalLM(cfg.model)
+        finally:
+            torch.set_default_dtype(prev)
+        self.model.eval()
+        if cfg.checkpoint_path:
+            from minivllm_amd.utils.loader import load_weights_from_checkpoint
+            load_weights_from_checkpoint(self.model, cfg.checkpoint_path)
+        else:
+            self.model.init_random_weights(cfg.seed)
+        self.sampler = SamplerLayer(seed=cfg.seed)
+        self.step_counter = 0
+        self.graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
+        self.graph_pool = None
+        self.kv_cache: Optional[torch.Tensor] = None
+        self.num_kv_blocks = 0
+
+        # ---- buffers -----------------------------------------------------
+        self.max_bs = cfg.max_num_sequences
+        self.max_blocks_per_seq = cfg.max_blocks_per_seq
+        self._init_buffers()
+
+        with torch.inference_mode():
+            self.warmup_model()
+            self.allocate_kv_cache()
+            if self.on_gpu and not self.enforce_eager:
+                self.capture_graphs()
+
+        # ---- control channel --------------------------------------------
+        self.channel: Optional[ShmBroadcastChannel] = None
+        if self.world_size > 1:
+            name = f"minivllm_amd_{cfg.master_port}"
+            if rank == 0:
+                self.channel = ShmBroadcastChannel(name, self.world_size - 1, create=True)
+                pg.tp_barrier()
+            else:
+                pg.tp_barrier()
+                self.channel = ShmBroadcastChannel(name, self.world_size - 1, create=False)
+                if spawn_loop:
+                    self.loop()
+
+    # ================================================================ buffers
+    def _init_buffers(self) -> None:
+        cfg = self.cfg
+        mb, MB = self.max_bs, self.max_blocks_per_seq
+        # decode: fixed layout so that graphs can bake the addresses in
+        self._dec_off = {}
+        off = 0
+        for name, n in (("input_ids", mb), ("positions", mb), ("slot_mapping", mb),
+                        ("context_lens", mb), ("temperatures", mb), ("misc", 4),
+                        ("block_tables", mb * MB)):
+            self._dec_off[name] = (off, n)
+            off += (n + 3) // 4 * 4
+        self._dec_words = off
+        # prefill: input_ids, positions, slot_mapping (T each) + cu_q, cu_k (B+1) + temps (B)
+        #          + misc + block tables
+        self._pre_words = 0          # grown on demand
+        pin = self.on_gpu
+        self._dec_host = torch.zeros(self._dec_words, dtype=torch.int32, pin_memory=pin)
+        self._dec_dev = torch.zeros(self._dec_words, dtype=torch.int32, device=self.device)
+        self._pre_host = None
+        self._pre_dev = None
+
+    def _ensure_prefill_buffers(self, words: int) -> None:
+        if self._pre_host is None or self._pre_host.numel() < words:
+            words = max(words, 3 * self.cfg.max_num_batched_tokens + 4096)
+            self._pre_host = torch.zeros(words, dtype=torch.int32, pin_memory=self.on_gpu)
+            self._pre_dev = torch.zeros(words, dtype=torch.int32, device=self.device)
+
+    def _dec_view(self, buf: torch.Tensor, name: str, n: Optional[int] = None) -> torch.Tensor:
+        off, size = self._dec_off[name]
+        return buf[off:off + (size if n is None else n)]
+
+    # ============================================================== RPC plumbing
+    def call(self, method_name: str, *args):
+        """Rank 0: run ``method`` here and on every worker (reference: model_runner.py:117-123)."""
+        if self.world_size > 1 and self.rank == 0 and method_name != "run":
+            self.channel.send(method_name, {"args": args})
+        return getattr(self, method_name)(*args)
+
+    def loop(self) -> None:
+        """Worker main loop: execute broadcast requests until ``exit``."""
+        while True:
+            method, scalars, arrays = self.channel.recv(self.rank - 1)
+            if method == "run_batch":
+                with torch.inference_mode():
+                    self.execute(Batch(arrays=arrays, **scalars))
+            elif method == "exit":
+                self.exit()
+                break
+            else:
+                getattr(self, method)(*scalars.get("args", ()))
+
+    def exit(self) -> None:
+        if getattr(self, "_exited", False):
+            return
+        self._exited = True
+        self.graphs.clear()
+        self.graph_pool = None
+        if self.on_gpu:
+            torch.cuda.synchronize()
+        if self.channel is not None:
+            try:                    # readers detach before the writer unlinks the segment
+                pg.tp_barrier()
+            except Exception:
+                pass
+            self.channel.close()
+            self.channel = None
+        pg.destroy_tensor_parallel()
+
+    # ================================================================ warm-up
+    def warmup_model(self) -> None:
+        """One prefill of the largest batch the scheduler can emit, without a KV cache, so
+        that peak activation memory is known before the cache is sized
+        (reference: model_runner.py:129-137)."""
+        if not self.on_gpu:
+            return
+        cfg = self.cfg
+        torch.cuda.empty_cache()
+        torch.cuda.reset_peak_memory_stats()
+        seq_len = min(cfg.max_model_length, cfg.max_num_batched_tokens)
+        num_seqs = max(1, min(cfg.max_num_batched_tokens // seq_len, cfg.max_num_sequences))
+        lens = [seq_len] * num_seqs
+        T = sum(lens)
+        cu = np.concatenate([[0], np.cumsum(lens)]).astype(np.int32)
+        batch = Batch(is_prefill=True, num_seqs=num_seqs, num_tokens=T, max_seqlen_q=seq_len,
+                      max_seqlen_k=seq_len, arrays=dict(
+                          input_ids=np.zeros(T, np.int32),
+                          positions=np.concatenate([np.arange(n) for n in lens]).astype(np.int32),
+                          slot_mapping=np.full(T, -1, np.int32),
+                          cu_seqlens_q=cu, cu_seqlens_k=cu,
+                          temperatures=np.zeros(num_seqs, np.float32),
+                          block_tables=np.zeros((num_seqs, 1), np.int32)))
+        self.execute(batch, warmup=True)
+        torch.cuda.synchronize()
+
+    # ================================================================ KV cache
+    def kv_block_bytes(self) -> int:
+        m = self.cfg.model
+        itemsize = torch.empty((), dtype=self.dtype).element_size()
+        return (2 * m.num_layers * self.block_size * (m.num_kv_heads // self.world_size)
+                * m.head_dim * itemsize)
+
+    def allocate_kv_cache(self) -> None:
+        cfg, m = self.cfg, self.cfg.model
+        block_bytes = self.kv_block_bytes()
+        if self.on_gpu:
+            free, total = torch.cuda.mem_get_info()
+            stats = torch.cuda.memory_stats()
+            peak = stats.get("allocated_bytes.all.peak", 0)
+            current = stats.get("allocated_bytes.all.current", 0)
+            used = total - free
+            # same accounting as the reference (model_runner.py:140-157): budget = total *
+            # utilisation - what is in use now - the activation head-room seen in warm-up
+            budget = int(total * cfg.gpu_memory_utilization) - used - max(peak - current, 0)
+            num_blocks = budget // block_bytes
+            if self.world_size > 1:        # every rank must agree on the block count
+                t = torch.tensor([num_blocks], dtype=torch.int64, device=self.device)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN,
+                                             group=pg.tp_group())
+                num_blocks = int(t.item())
+        else:
+            budget = 256 << 20
+            num_blocks = max(budget // block_bytes, 8)
+        if not self.on_gpu:
+            # no sequence set can use more than this many blocks at once
+            num_blocks = min(num_blocks, cfg.max_num_sequences * (cfg.max_blocks_per_seq + 1))
+        if cfg.max_cached_blocks is not None:
+            num_blocks = min(num_blocks, cfg.max_cached_blocks)
+        if num_blocks <= 0:
+            raise RuntimeError("not enough device memory for a single KV-cache block")
+        self.num_kv_blocks = int(num_blocks)
+        hkv = m.num_kv_heads // self.world_size
+        # physical order [2, layer, block, kv_head, token, d]; layers see the logical
+        # [block, token, kv_head, d] view of it
+        self.kv_cache = torch.zeros(2, m.num_layers, self.num_kv_blocks, hkv, self.block_size,
+                                    m.head_dim, dtype=self.dtype, device=self.device)
+        for i, layer in enumerate(self.model.model.layers):
+            attn = layer.self_attn.attn
+            attn.k_cache = self.kv_cache[0, i].permute(0, 2, 1, 3)
+            attn.v_cache = self.kv_cache[1, i].permute(0, 2, 1, 3)
+            attn.block_size = self.block_size
+
+    # ============================================================ batch building
+    def prepare_prefill(self, seqs: Seq[Sequence]) -> Batch:
+        bs = self.block_size
+        ids, pos, slots, cu_q, cu_k = [], [], [], [0], [0]
+        max_q = max_k = 0
+        has_prefix = False
+        for seq in seqs:
+            start, end = seq.num_cached_tokens, seq.num_tokens
+            has_prefix |= start > 0
+            p = np.arange(start, end, dtype=np.int32)
+            bt = np.asarray(seq.block_table, dtype=np.int32)
+            ids.append(np.asarray(seq.token_ids[start:end], dtype=np.int32))
+            pos.append(p)
+            slots.append(bt[p // bs] * bs + p % bs)
+            cu_q.append(cu_q[-1] + end - start)
+            cu_k.append(cu_k[-1] + end)
+            max_q, max_k = max(max_q, end - start), max(max_k, end)
+        B = len(seqs)
+        MB = max(len(s.block_table) for s in seqs)
+        tables = np.full((B, MB), -1, np.int32)
+        for i, s in enumerate(seqs):
+            tables[i, :len(s.block_table)] = s.block_table
+        input_ids = np.concatenate(ids)
+        return Batch(is_prefill=True, num_seqs=B, num_tokens=int(input_ids.size),
+                     max_seqlen_q=max_q, max_seqlen_k=max_k, has_prefix=has_prefix,
+                     arrays=dict(input_ids=input_ids, positions=np.concatenate(pos),
+                                 slot_mapping=np.concatenate(slots).astype(np.int32),
+                                 cu_seqlens_q=np.asarray(cu_q, np.int32),
+                                 cu_seqlens_k=np.asarray(cu_k, np.int32),
+                                 temperatures=np.asarray([s.temperature for s in seqs], np.float32),
+                                 block_tables=tables))
+
+    def prepare_decode(self, seqs: Seq[Sequence]) -> Batch:
+        bs = self.block_size
+        B = len(seqs)
+        lens = np.fromiter((s.num_tokens for s in seqs), np.int32, B)
+        last_block = np.fromiter((s.block_table[-1] for s in seqs), np.int32, B)
+        MB = max(len(s.block_table) for s in seqs)
+        tables = np.full((B, MB), -1, np.int32)
+        for i, s in enumerate(seqs):
+            tables[i, :len(s.block_table)] = s.block_table
+        pos = lens - 1
+        return Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1,
+                     max_seqlen_k=int(lens.max()), max_context_len=int(lens.max()),
+                     arrays=dict(input_ids=np.fromiter((s.last_token for s in seqs), np.int32, B),
+                                 positions=pos, slot_mapping=last_block * bs + pos % bs,
+                                 context_lens=lens,
+                                 temperatures=np.fromiter((s.temperature for s in seqs), np.float32, B),
+                                 block_tables=tables))
+
+    def prepare_sample(self, seqs: Seq[Sequence]) -> torch.Tensor:
+        return torch.tensor([s.temperature for s in seqs], dtype=torch.float32, device=self.device)
+
+    # ================================================================== run
+    def run(self, seqs: Seq[Sequence], is_prefill: bool) -> Optional[List[int]]:
+        """Rank 0 entry point for one step; returns the sampled token per sequence."""
+        batch = self.prepare_prefill(seqs) if is_prefill else self.prepare_decode(seqs)
+        self.step_counter += 1
+        batch.step = self.step_counter
+        if self.world_size > 1 and self.rank == 0:
+            self.channel.send("run_batch", batch.scalars(), batch.arrays)
+        with torch.inference_mode():
+            return self.execute(batch)
+
+    # ------------------------------------------------------------- uploads
+    def _upload_prefill(self, b: Batch):
+        a = b.arrays
+        T, B = b.num_tokens, b.num_seqs
+        MB = a["block_tables"].shape[1]
+        al = lambda n: (n + 3) // 4 * 4
+        layout, off = {}, 0
+        for name, n in (("input_ids", T), ("positions", T), ("slot_mapping", T),
+                        ("cu_seqlens_q", B + 1), ("cu_seqlens_k", B + 1), ("temperatures", B),
+                        ("misc", 4), ("block_tables", B * MB)):
+            layout[name] = (off, n)
+            off += al(n)
+        self._ensure_prefill_buffers(off)
+        host = self._pre_host.numpy()
+        for name, (o, n) in layout.items():
+            if name == "misc":
+                host[o] = b.step
+            elif name == "temperatures":
+                host[o:o + n] = a[name].astype(np.float32).view(np.int32)
+            else:
+                host[o:o + n] = a[name].reshape(-1)
+        self._pre_dev[:off].copy_(self._pre_host[:off], non_blocking=True)
+        v = lambda name: self._pre_dev[layout[name][0]:layout[name][0] + layout[name][1]]
+        return dict(input_ids=v("input_ids"), positions=v("positions"),
+                    slot_mapping=v("slot_mapping"), cu_seqlens_q=v("cu_seqlens_q"),
+                    cu_seqlens_k=v("cu_seqlens_k"),
+                    temperatures=v("temperatures").view(torch.float32),
+                    step=v("misc"), block_tables=v("block_tables").view(B, MB))
+
+    def _fill_decode_host(self, b: Batch, padded_bs: int) -> None:
+        a = b.arrays
+        B = b.num_seqs
+        MBmax = self.max_blocks_per_seq
+        host = self._dec_host.numpy()
+
+        def put(name, values, fill):
+            off, _ = self._dec_off[name]
+            host[off:off + B] = values
+            if padded_bs > B:
+                host[off + B:off + padded_bs] = fill
+        put("input_ids", a["input_ids"], 0)
+        put("positions", a["positions"], 0)
+        put("slot_mapping", a["slot_mapping"], -1)
+        put("context_lens", a["context_lens"], 0)
+        put("temperatures", a["temperatures"].astype(np.float32).view(np.int32), 0)
+        host[self._dec_off["misc"][0]] = b.step
+        off, _ = self._dec_off["block_tables"]
+        tab = host[off:off + padded_bs * MBmax].reshape(padded_bs, MBmax)
+        mb = a["block_tables"].shape[1]
+        if mb > MBmax:
+            raise RuntimeError("sequence uses more KV blocks than max_model_length allows")
+        tab[:B, :mb] = a["block_tables"]
+        tab[:B, mb:] = -1
+        if padded_bs > B:
+            tab[B:] = -1
+
+    def _decode_tensors(self, n: int):
+        d = self._dec_dev
+        MB = self.max_blocks_per_seq
+        return dict(input_ids=self._dec_view(d, "input_ids", n),
+                    positions=self._dec_view(d, "positions", n),
+                    slot_mapping=self._dec_view(d, "slot_mapping", n),
+                    context_lens=self._dec_view(d, "context_lens", n),
+                    temperatures=self._dec_view(d, "temperatures", n).view(torch.float32),
+                    step=self._dec_view(d, "misc"),
+                    block_tables=self._dec_view(d, "block_tables", n * MB).view(n, MB))
+
+    # -------------------------------------------------------------- execute
+    def execute(self, b: Batch, warmup: bool = False) -> Optional[List[int]]:
+        if b.is_prefill:
+            t = self._upload_prefill(b)
+            set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
+                        max_seqlen_q=b.max_seqlen_q, max_seqlen_k=b.max_seqlen_k,
+                        slot_mapping=None if warmup else t["slot_mapping"],
+                        block_tables=None if warmup else t["block_tables"],
+                        positions=t["positions"], num_seqs=b.num_seqs, has_prefix=b.has_prefix)
+            tokens = self._forward_and_sample(t)
+        else:
+            B = b.num_seqs
+            bucket = self._graph_bucket(B)
+            padded = bucket if bucket is not None else B
+            self._fill_decode_host(b, padded)
+            self._dec_dev.copy_(self._dec_host, non_blocking=True)
+            if bucket is not None:
+                self.graphs[bucket].replay()
+                tokens = self._graph_out[bucket][:B]
+            else:
+                t = self._decode_tensors(B)
+                set_context(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
+                            block_tables=t["block_tables"], positions=t["positions"],
+                            max_context_len=b.max_context_len, num_seqs=B)
+                tokens = self._forward_and_sample(t)
+        reset_context()
+        if warmup or tokens is None or self.rank != 0:
+            return None
+        return tokens.tolist()
+
+    def _graph_bucket(self, B: int) -> Optional[int]:
+        if not self.graphs:
+            return None
+        for s in self._graph_sizes:
+            if s >= B:
+                return s
+        return None
+
+    def _forward_and_sample(self, t: dict) -> Optional[torch.Tensor]:
+        hidden = self.model(t["input_ids"], t["positions"])
+        return self._sample(hidden, t["temperatures"], t["step"])
+
+    def _sample(self, hidden: torch.Tensor, temperatures: torch.Tensor,
+                step: torch.Tensor) -> Optional[torch.Tensor]:
+        if self.on_gpu:
+            from minivllm_amd.ops import hip
+            head = self.model.lm_head
+            logits = head.local_logits(hidden)
+            vals, idx = hip.sample_local(logits, temperatures, self.cfg.seed, step,
+                                         vocab_offset=head.vocab_start,
+                                         valid_vocab=head.num_embeddings)
+            if self.world_size == 1:
+                return idx
+            pair = torch.stack([vals, idx.to(torch.float32)], dim=-1)          # [B, 2]
+            allp = [torch.empty_like(pair) for _ in range(self.world_size)]
+            torch.distributed.all_gather(allp, pair, group=pg.tp_group())
+            allp = torch.stack(allp)                                            # [tp, B, 2]
+            best = allp[..., 0].argmax(dim=0)
+            return allp[..., 1].gather(0, best[None]).squeeze(0).to(torch.int32)
+        logits = self.model.compute_logits(hidden)
+        if logits is None:
+            return None
+        return self.sampler(logits, temperatures)
+
+    # ================================================================ graphs
+    @torch.inference_mode()
+    def capture_graphs(self) -> None:
+        """Capture one hipGraph per decode batch-size bucket, largest first so that all
+        graphs share one memory pool (same policy as reference model_runner.py:316-369)."""
+        sizes = self.cfg.graph_batch_sizes or default_graph_batch_sizes(self.max_bs)
+        self._graph_sizes = sorted(sizes)
+        self._graph_out: Dict[int, torch.Tensor] = {}
+        # a harmless decode batch: every row is padding (context 0, slot -1)
+        host = self._dec_host.numpy()
+        host[:] = 0
+        o, n = self._dec_off["slot_mapping"]
+        host[o:o + n] = -1
+        o, n = self._dec_off["block_tables"]
+        host[o:o + n] = -1
+        self._dec_dev.copy_(self._dec_host)
+        for bs in reversed(self._graph_sizes):
+            t = self._decode_tensors(bs)
+
+            def step():
+                set_context(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
+                            block_tables=t["block_tables"], positions=t["positions"],
+                            max_context_len=self.cfg.max_model_length, num_seqs=bs)
+                out = self._forward_and_sample(t)
+                reset_context()
+                return out
+            step()                                   # warm-up outside capture
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph_pool):
+                out = step()
+            if self.graph_pool is None:
+                self.graph_pool = g.pool()
+            self.graphs[bs] = g
+            self._graph_out[bs] = out
+        torch.cuda.synchronize()

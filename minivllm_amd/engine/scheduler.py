@@ -1,0 +1,137 @@
+"""Continuous-batching scheduler: prefill first, otherwise one decode token per
+running sequence, recompute-style preemption when KV blocks run out.
+
+Policy follows the reference (reference: src/myvllm/engine/scheduler.py:6-82):
+two queues, head-of-line prefill admission under a sequence budget and a token
+budget, LIFO victim selection for preemption, preempted sequences go back to the
+*front* of the waiting queue and are re-prefetched from scratch.  Corrected
+relative to the reference: sampled tokens go through ``Sequence.append_token`` so
+lengths advance and ``max_tokens`` triggers; a decode candidate that does not fit
+the step's budget stays in the running queue instead of being dropped; prompts
+that can never be scheduled are rejected when they are added.
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import Deque, List, Optional, Tuple
+
+from .block_manager import BlockManager
+from .sequence import Sequence, SequenceStatus
+
+
+class Scheduler:
+    def __init__(self, max_num_sequences: int, max_num_batched_tokens: int,
+                 max_cached_blocks: int, block_size: int, eos: int,
+                 max_model_length: Optional[int] = None):
+        self.block_manager = BlockManager(max_cached_blocks, block_size)
+        self.max_num_sequences = max_num_sequences
+        self.max_num_batched_tokens = max_num_batched_tokens
+        self.max_model_length = max_model_length
+        self.block_size = block_size
+        self.eos = eos
+        self.waiting: Deque[Sequence] = deque()
+        self.running: Deque[Sequence] = deque()
+        self.num_preemptions = 0
+
+    def is_finished(self) -> bool:
+        return not self.waiting and not self.running
+
+    def add_sequence(self, seq: Sequence) -> None:
+        seq.block_size = self.block_size
+        limit = self.max_num_batched_tokens
+        # a preempted sequence is re-prefetched with its generated tokens, so the
+        # whole request (prompt + max_tokens) must fit one prefill step
+        worst = seq.num_prompt_tokens + seq.max_tokens
+        if seq.num_prompt_tokens > limit:
+            raise ValueError(
+                f"prompt of {seq.num_prompt_tokens} tokens exceeds max_num_batched_tokens={limit}")
+        if self.max_model_length is not None and worst > self.max_model_length:
+            raise ValueError(
+                f"prompt ({seq.num_prompt_tokens}) + max_tokens ({seq.max_tokens}) exceeds "
+                f"max_model_length={self.max_model_length}")
+        need = (worst + self.block_size - 1) // self.block_size
+        if need > self.block_manager.num_blocks:
+            raise ValueError(
+                f"request needs {need} KV blocks but the cache has {self.block_manager.num_blocks}")
+        self.waiting.append(seq)
+
+    # ------------------------------------------------------------- schedule
+    def schedule(self) -> Tuple[List[Sequence], bool]:
+        scheduled: List[Sequence] = []
+        num_tokens = 0
+        bm = self.block_manager
+
+        # phase 1: admit waiting sequences (prefill) in arrival order
+        while self.waiting and len(scheduled) < self.max_num_sequences:
+            seq = self.waiting[0]
+            if num_tokens + len(seq) > self.max_num_batched_tokens and scheduled:
+                break
+            if len(seq) > self.max_num_batched_tokens:
+                # grew past one step's budget while it was running and was then
+                # preempted; let it through alone rather than stall forever
+                if scheduled:
+                    break
+            if not bm.can_allocate(seq):
+                break
+            if len(self.running) >= self.max_num_sequences:
+                break
+            self.waiting.popleft()
+            bm.allocate(seq)
+            seq.status = SequenceStatus.RUNNING
+            self.running.append(seq)
+            scheduled.append(seq)
+            num_tokens += len(seq) - seq.num_cached_tokens
+        if scheduled:
+            return scheduled, True
+
+        # phase 2: one token for every running sequence, oldest first
+        candidates = self.running
+        self.running = deque()
+        deferred: List[Sequence] = []
+        while candidates:
+            seq = candidates.popleft()
+            if len(scheduled) >= self.max_num_sequences or num_tokens >= self.max_num_batched_tokens:
+                deferred.append(seq)
+                continue
+            preempted_self = False
+            while not bm.can_append(seq):
+                if candidates:
+                    self.preempt(candidates.pop())      # newest sequence is the victim
+                elif deferred:
+                    self.preempt(deferred.pop())
+                else:
+                    self.preempt(seq)
+                    preempted_self = True
+                    break
+            if preempted_self:
+                continue
+            bm.append(seq)
+            scheduled.append(seq)
+            num_tokens += 1
+        self.running.extend(scheduled)
+        self.running.extend(deferred)
+        return scheduled, False
+
+    def preempt(self, seq: Sequence) -> None:
+        self.block_manager.deallocate(seq)
+        seq.status = SequenceStatus.WAITING
+        self.waiting.appendleft(seq)
+        self.num_preemptions += 1
+
+    # ---------------------------------------------------------- postprocess
+    def postprocess(self, seqs: List[Sequence], token_ids: List[int]) -> List[Sequence]:
+        finished = []
+        for seq, token_id in zip(seqs, token_ids):
+            seq.append_token(int(token_id))
+            hit_eos = (not seq.ignore_eos) and token_id == self.eos
+            hit_len = seq.num_completion_tokens >= seq.max_tokens
+            hit_ctx = (self.max_model_length is not None
+                       and seq.num_tokens >= self.max_model_length)
+            if hit_eos or hit_len or hit_ctx:
+                seq.status = SequenceStatus.FINISHED
+                self.block_manager.deallocate(seq)
+                finished.append(seq)
+        if finished:
+            done = {id(s) for s in finished}
+            self.running = deque(s for s in self.running if id(s) not in done)
+        return finished

@@ -1,0 +1,93 @@
+"""Attention layer over a paged KV cache, plus the three kernel entry points the
+reference exposes.
+
+Reference (src/myvllm/layers/attention.py:67-108, 212-280, 418-473, 476-557):
+``store_kvcache`` scatters new K/V rows into the cache, prefill runs a varlen
+causal flash-attention over the *new* tokens only (so a cached prefix is silently
+ignored), decode runs one-query paged attention with a ``block_size`` that is
+never wired to the engine's.  Here the cache tensor itself defines the block
+size, prefill attends through the block table whenever a cache is attached
+(``q_len <= k_len``, so prefix-cache hits and re-prefill after preemption are
+exact), and K/V are written by the fused norm+RoPE+store kernel upstream, not by
+this layer.
+
+Cache tensors are logically ``[num_blocks, block_size, num_kv_heads, head_dim]``;
+the engine allocates them with a head-major physical order so that one
+(block, kv-head) pair is one contiguous slab for the decode kernel.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from minivllm_amd import ops
+from minivllm_amd.utils.context import get_context
+
+
+# ----------------------------------------------- reference-signature functions
+def store_kvcache(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor,
+                  v_cache: torch.Tensor, slot_mapping: torch.Tensor,
+                  block_size: Optional[int] = None) -> None:
+    if block_size is not None and block_size != k_cache.shape[1]:
+        raise ValueError(f"block_size={block_size} does not match the cache ({k_cache.shape[1]})")
+    ops.store_kvcache(key, value, k_cache, v_cache, slot_mapping)
+
+
+def flash_attention_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                            cu_seqlens: torch.Tensor, scale: float,
+                            num_heads: Optional[int] = None, num_kv_heads: Optional[int] = None,
+                            head_dim: Optional[int] = None,
+                            max_seqlen: Optional[int] = None) -> torch.Tensor:
+    """q [T,Hq,D], k/v [T,Hkv,D], causal, packed by ``cu_seqlens``.  ``scale`` is the
+    full softmax scale (1/sqrt(D) already included)."""
+    return ops.flash_attention_prefill(q, k, v, cu_seqlens, scale, max_seqlen)
+
+
+def paged_attention_decode(query: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                           block_tables: torch.Tensor, context_lens: torch.Tensor, scale: float,
+                           num_heads: Optional[int] = None, num_kv_heads: Optional[int] = None,
+                           head_dim: Optional[int] = None, block_size: Optional[int] = None,
+                           max_context_len: Optional[int] = None) -> torch.Tensor:
+    if block_size is not None and block_size != k_cache.shape[1]:
+        raise ValueError(f"block_size={block_size} does not match the cache ({k_cache.shape[1]})")
+    return ops.paged_attention_decode(query, k_cache, v_cache, block_tables, context_lens, scale,
+                                      max_context_len)
+
+
+# --------------------------------------------------------------------- layer
+class Attention(nn.Module):
+    def __init__(self, num_heads: int, head_dim: int, scale: float = 1.0,
+                 num_kv_heads: Optional[int] = None, block_size: Optional[int] = None):
+        super().__init__()
+        self.num_heads = num_heads
+        self.head_dim = head_dim
+        self.num_kv_heads = num_kv_heads or num_heads
+        # like the reference, ``scale`` multiplies 1/sqrt(head_dim) (attention.py:512)
+        self.scale = scale / math.sqrt(head_dim)
+        self.block_size = block_size
+        self.k_cache: Optional[torch.Tensor] = None
+        self.v_cache: Optional[torch.Tensor] = None
+
+    def forward(self, q: torch.Tensor, k: Optional[torch.Tensor] = None,
+                v: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """q [T,Hq,D] (rows may be strided); k/v [T,Hkv,D] are only read when no cache
+        is attached.  Returns [T, Hq*D]."""
+        ctx = get_context()
+        T = q.shape[0]
+        if ctx.is_prefill:
+            if self.k_cache is not None and ctx.block_tables is not None:
+                o = ops.paged_attention_prefill(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q,
+                                                ctx.cu_seqlens_k, ctx.block_tables, self.scale,
+                                                ctx.max_seqlen_q)
+            else:
+                o = ops.flash_attention_prefill(q, k, v, ctx.cu_seqlens_q, self.scale,
+                                                ctx.max_seqlen_q)
+        else:
+            if self.k_cache is None:
+                raise RuntimeError("decode needs an allocated KV cache")
+            o = ops.paged_attention_decode(q, self.k_cache, self.v_cache, ctx.block_tables,
+                                           ctx.context_lens, self.scale, ctx.max_context_len)
+        return o.reshape(T, self.num_heads * self.head_dim)

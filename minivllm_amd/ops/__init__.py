@@ -1,0 +1,75 @@
+"""Device-op entry points.  Exactly two implementations exist: ``hip`` (hand-written
+gfx950 kernels, used for every CUDA/HIP tensor) and ``torch_ref`` (plain PyTorch,
+used on CPU and as the test oracle).  A GPU tensor never falls back to
+``torch_ref``: if the compiled kernel library is missing the call raises.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import torch_ref
+
+
+def _hip():
+    from . import hip        # raises with a build hint when the .so is absent
+    return hip
+
+
+def _on_gpu(t: torch.Tensor) -> bool:
+    return t.is_cuda
+
+
+def rms_norm(x, weight, eps):
+    return _hip().rms_norm(x, weight, eps) if _on_gpu(x) else torch_ref.rms_norm(x, weight, eps)
+
+
+def add_rms_norm(x, residual, weight, eps):
+    if _on_gpu(x):
+        return _hip().add_rms_norm(x, residual, weight, eps)
+    return torch_ref.add_rms_norm(x, residual, weight, eps)
+
+
+def silu_and_mul(x):
+    return _hip().silu_and_mul(x) if _on_gpu(x) else torch_ref.silu_and_mul(x)
+
+
+def qk_norm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, num_heads, num_kv_heads,
+                       head_dim, k_cache, v_cache, slot_mapping):
+    f = _hip().qk_norm_rope_store if _on_gpu(qkv) else torch_ref.qk_norm_rope_store
+    return f(qkv, positions, cos_sin, q_weight, k_weight, eps, num_heads, num_kv_heads, head_dim,
+             k_cache, v_cache, slot_mapping)
+
+
+def store_kvcache(key, value, k_cache, v_cache, slot_mapping):
+    f = _hip().store_kvcache if _on_gpu(key) else torch_ref.store_kvcache
+    return f(key, value, k_cache, v_cache, slot_mapping)
+
+
+def flash_attention_prefill(q, k, v, cu_seqlens, scale, max_seqlen=None):
+    if _on_gpu(q):
+        return _hip().flash_attention_prefill(q, k, v, cu_seqlens, scale, max_seqlen)
+    return torch_ref.flash_attention_prefill(q, k, v, cu_seqlens, scale)
+
+
+def paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k, block_tables, scale,
+                            max_seqlen_q=None):
+    if _on_gpu(q):
+        return _hip().paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k,
+                                              block_tables, scale, max_seqlen_q)
+    return torch_ref.paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k,
+                                             block_tables, scale)
+
+
+def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scale,
+                           max_context_len=None):
+    if _on_gpu(q):
+        return _hip().paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens,
+                                             scale, max_context_len)
+    return torch_ref.paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scale)
+
+
+def sample(logits, temperatures, seed=0, step=0, generator=None):
+    """Returns int64 token ids [B]."""
+    if _on_gpu(logits):
+        return _hip().sample(logits, temperatures, seed, step)
+    return torch_ref.sample(logits, temperatures, generator)

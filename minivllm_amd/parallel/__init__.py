@@ -1,0 +1,3 @@
+from .group import (init_tensor_parallel, destroy_tensor_parallel, set_tp_for_testing, tp_rank,
+                    tp_size, tp_group, tp_all_reduce, tp_all_gather, tp_gather, tp_barrier,
+                    env_rank_world, is_initialized)

@@ -1,0 +1,120 @@
+"""Tensor-parallel process group: one process per GPU, RCCL over xGMI.
+
+The reference creates an NCCL group on a fixed ``tcp://localhost:12345`` even for
+a single GPU and layers query ``dist.get_rank()`` in their constructors
+(reference: src/myvllm/engine/model_runner.py:24, layers/linear.py:20-21).  Here
+the group is explicit state: ``world_size == 1`` never touches
+``torch.distributed`` (which is also what lets the engine run on a CPU-only
+machine), the rendezvous address is configurable, and the backend is ``nccl``
+(= RCCL on ROCm) for GPU ranks and ``gloo`` for CPU ranks.
+"""
+from __future__ import annotations
+
+import datetime
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+_TP_RANK = 0
+_TP_SIZE = 1
+_TP_GROUP: Optional[dist.ProcessGroup] = None
+_OWNS_DEFAULT_GROUP = False
+
+
+def tp_rank() -> int:
+    return _TP_RANK
+
+
+def tp_size() -> int:
+    return _TP_SIZE
+
+
+def tp_group():
+    return _TP_GROUP
+
+
+def is_initialized() -> bool:
+    return _TP_SIZE > 1 and _TP_GROUP is not None
+
+
+def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
+                         master_addr: str = "127.0.0.1", master_port: int = 29512,
+                         device: Optional[torch.device] = None,
+                         timeout_s: float = 600.0) -> None:
+    """Join the TP group.  Reuses an already initialised default group (torchrun)."""
+    global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP
+    _TP_RANK, _TP_SIZE = rank, world_size
+    if world_size == 1:
+        _TP_GROUP = None
+        return
+    if backend == "auto":
+        backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+    if not dist.is_initialized():
+        kwargs = {}
+        if backend == "nccl" and device is not None:
+            kwargs["device_id"] = torch.device(device)
+        dist.init_process_group(
+            backend=backend, init_method=f"tcp://{master_addr}:{master_port}",
+            world_size=world_size, rank=rank,
+            timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
+        _OWNS_DEFAULT_GROUP = True
+    else:
+        assert dist.get_world_size() == world_size and dist.get_rank() == rank
+    _TP_GROUP = dist.group.WORLD
+
+
+def set_tp_for_testing(rank: int, world_size: int) -> None:
+    """Shard-math tests build layers for an arbitrary (rank, size) without any
+    communication backend."""
+    global _TP_RANK, _TP_SIZE, _TP_GROUP
+    _TP_RANK, _TP_SIZE, _TP_GROUP = rank, world_size, None
+
+
+def destroy_tensor_parallel() -> None:
+    global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP
+    if _TP_GROUP is not None and _OWNS_DEFAULT_GROUP and dist.is_initialized():
+        dist.destroy_process_group()
+    _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP = 0, 1, None, False
+
+
+# ------------------------------------------------------------- collectives
+def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
+    """In-place sum over the TP group; returns ``x`` (the reference returns the
+    collective's return value instead of the tensor: layers/linear.py:218-219)."""
+    if _TP_GROUP is not None:
+        dist.all_reduce(x, group=_TP_GROUP)
+    return x
+
+
+def tp_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
+    if _TP_GROUP is None:
+        return x
+    parts: List[torch.Tensor] = [torch.empty_like(x) for _ in range(_TP_SIZE)]
+    dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)
+    return torch.cat(parts, dim=dim)
+
+
+def tp_gather(x: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Tensor]:
+    """Concatenate shards on ``dst``; other ranks get None (reference:
+    layers/embedding_head.py:67-75)."""
+    if _TP_GROUP is None:
+        return x
+    x = x.contiguous()
+    parts = [torch.empty_like(x) for _ in range(_TP_SIZE)] if _TP_RANK == dst else None
+    dist.gather(x, parts, dst=dst, group=_TP_GROUP)
+    return torch.cat(parts, dim=dim) if parts is not None else None
+
+
+def tp_barrier() -> None:
+    if _TP_GROUP is not None:
+        dist.barrier(group=_TP_GROUP)
+
+
+def env_rank_world() -> tuple:
+    """(rank, local_rank, world_size) from a torchrun-style environment, or (0,0,1)."""
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:
+        return (int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", os.environ["RANK"])),
+                int(os.environ["WORLD_SIZE"]))
+    return 0, 0, 1

@@ -1,0 +1,28 @@
+"""Per-request sampling parameters.
+
+Superset of the reference's ``SamplingParams(temperature, max_tokens, ignore_eos)``
+(reference: src/myvllm/sampling_parameters.py:4-11).  The reference forbids
+greedy sampling; here ``temperature == 0`` selects arg-max decoding, which the
+CPU plumbing configuration needs for token-exact comparisons.
+"""
+from dataclasses import dataclass
+
+
+@dataclass
+class SamplingParams:
+    temperature: float = 1.0
+    max_tokens: int = 64
+    ignore_eos: bool = False
+
+    def __post_init__(self):
+        if self.temperature < 0:
+            raise ValueError("temperature must be >= 0 (0 selects greedy decoding)")
+        if 0 < self.temperature < 1e-5:
+            # tiny temperatures overflow logits / T in bf16; treat them as greedy
+            self.temperature = 0.0
+        if self.max_tokens < 1:
+            raise ValueError("max_tokens must be >= 1")
+
+    @property
+    def greedy(self) -> bool:
+        return self.temperature == 0.0

@@ -1,0 +1,48 @@
+"""Per-step forward context shared between the runner and the layers.
+
+Same role and field names as the reference's module-global dataclass
+(reference: src/myvllm/utils/context.py:5-27).  Two additions remove the
+per-layer device->host synchronisations the reference performs
+(qwen3.py:199-206, attention.py:263-264): ``positions`` is computed once per
+step on the host, and ``max_seqlen_*`` / ``max_context_len`` are plain ints.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+
+@dataclass
+class Context:
+    is_prefill: bool = False
+    cu_seqlens_q: Optional[torch.Tensor] = None   # [B+1] int32, new (uncached) tokens
+    cu_seqlens_k: Optional[torch.Tensor] = None   # [B+1] int32, full lengths
+    max_seqlen_q: int = 0
+    max_seqlen_k: int = 0
+    slot_mapping: Optional[torch.Tensor] = None   # [T] int32, -1 = do not store
+    context_lens: Optional[torch.Tensor] = None   # [B] int32 (decode)
+    block_tables: Optional[torch.Tensor] = None   # [B, max_blocks] int32, -1 padded
+    positions: Optional[torch.Tensor] = None      # [T] int32 rotary positions
+    max_context_len: int = 0                      # decode: upper bound of context_lens
+    num_seqs: int = 0
+    has_prefix: bool = False                      # prefill reads a cached prefix
+
+
+_CONTEXT = Context()
+
+
+def get_context() -> Context:
+    return _CONTEXT
+
+
+def set_context(is_prefill: bool = False, **kw) -> Context:
+    global _CONTEXT
+    _CONTEXT = Context(is_prefill=is_prefill, **kw)
+    return _CONTEXT
+
+
+def reset_context() -> None:
+    global _CONTEXT
+    _CONTEXT = Context()
