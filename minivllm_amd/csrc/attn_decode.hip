@@ -1,0 +1,302 @@
+// Paged-attention decode for gfx950: one query token per sequence against a block-table
+// addressed KV cache.
+//
+// The reference kernel runs one Triton program per (sequence, QUERY head) with a scalar
+// per-token loop: a block-table lookup and a D-vector load per token, K and V in separate
+// passes, no sharing between the query heads of one KV head and no split over the context
+// (reference: src/myvllm/layers/attention.py:283-473).  This kernel is organised around the
+// KV stream instead, which is what bounds decode on HBM3E:
+//
+//  * one workgroup (4 waves) serves ALL query heads that share a KV head (up to 16 per
+//    group), so every K/V byte is fetched once per sequence, not once per query head;
+//  * grid = (context splits, KV heads, sequences); each wave walks its own 32-token tiles
+//    and keeps a private online-softmax state, the 4 waves and then the splits are merged
+//    flash-decoding style, so small batches still fill 256 CUs;
+//  * a tile is fetched with 16-byte-per-lane coalesced loads (a (block, kv-head) slab is
+//    contiguous in the engine's cache layout), staged through wave-private LDS (no
+//    workgroup barrier in the loop) and prefetched one tile ahead in registers, block-table
+//    entries two tiles ahead;
+//  * both products run on MFMA 16x16x32: S^T = K . Q^T puts the query head on the lane and
+//    the token on the accumulator rows, which is already the B-operand layout of
+//    O^T = V^T . P^T, and V^T fragments come from ds_read_b64_tr_b16 (hardware transpose);
+//  * the grid does not depend on context lengths (rows with length 0 exit immediately), so
+//    a launch can be captured in a hipGraph and replayed for any batch content.
+#include "common.h"
+
+using namespace mvl;
+
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+namespace {
+
+constexpr int kTile = 32;          // tokens per wave iteration
+constexpr int kWaves = 4;
+
+template <int CODE, int D>
+__global__ __launch_bounds__(256) void paged_decode_kernel(
+        const uint16_t* __restrict__ q, long q_stride_b, long q_stride_h,
+        const uint16_t* __restrict__ k_cache, const uint16_t* __restrict__ v_cache,
+        long cs_b, long cs_t, long cs_h, const int* __restrict__ block_tables, int bt_stride,
+        const int* __restrict__ context_lens, uint16_t* __restrict__ out, long o_stride_b,
+        long o_stride_h, float* __restrict__ part_acc, float* __restrict__ part_ml,
+        float scale_log2, int Hq, int Hkv, int bs_log2, int nsplit) {
+    using DT = DType<CODE>;
+    using vec8 = typename DT::vec8;
+    constexpr int CPR = D / 8;                 // 16-byte chunks per row
+    constexpr int ITER = kTile * CPR / 64;     // staging loads per lane per tile
+    constexpr int KSTEPS = D / 32;
+    constexpr int NDB = D / 16;
+    constexpr int TILE_BYTES = kTile * D * 2;
+    constexpr int WAVE_LDS = 2 * TILE_BYTES;
+    constexpr int ACC_LD = D + 4;              // padded row of the merge buffer (floats)
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c16 = lane & 15;                 // query head within the group / token row
+    const int q4 = lane >> 4;
+    char* k_lds = smem + w * WAVE_LDS;
+    char* v_lds = k_lds + TILE_BYTES;
+
+    const int split = blockIdx.x;
+    const int G = Hq / Hkv;
+    const int ngrp = (G + 15) >> 4;
+    const int kvh = blockIdx.y / ngrp;
+    const int hg = blockIdx.y - kvh * ngrp;
+    const int b = blockIdx.z;
+    const int head0 = kvh * G + hg * 16;
+    const int nheads = min(16, G - hg * 16);
+    const int L = context_lens[b];
+    const int bs_mask = (1 << bs_log2) - 1;
+
+    const int total_tiles = (L + kTile - 1) / kTile;
+    const int tps = (total_tiles + nsplit - 1) / nsplit;
+    const int t0 = split * tps;
+    const int t1 = min(t0 + tps, total_tiles);
+
+    // ---- Q^T fragments (B operand): lane holds Q[head c16][32 s + 8 q4 .. +7]
+    vec8 qfrag[KSTEPS];
+    {
+        const uint16_t* qp = q + b * q_stride_b + (long)(head0 + (c16 < nheads ? c16 : 0)) * q_stride_h;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            u32x4_t v = {0, 0, 0, 0};
+            if (c16 < nheads) v = *reinterpret_cast<const u32x4_t*>(qp + 32 * s + 8 * q4);
+            qfrag[s] = __builtin_bit_cast(vec8, v);
+        }
+    }
+
+    const int* bt = block_tables + (long)b * bt_stride;
+    const long head_off = (long)kvh * cs_h;
+
+    // per-lane staging coordinates: chunk id = i*64 + lane -> (row, ch)
+    int st_row[ITER], st_ch[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int c = i * 64 + lane;
+        st_row[i] = c / CPR;
+        st_ch[i] = c % CPR;
+    }
+
+    auto load_block_ids = [&](int tile, int (&ids)[ITER]) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int tok = min(tile * kTile + st_row[i], L - 1);
+            ids[i] = bt[tok >> bs_log2];
+        }
+    };
+    auto issue_loads = [&](int tile, const int (&ids)[ITER], u32x4_t (&kr)[ITER], u32x4_t (&vr)[ITER]) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int tok = min(tile * kTile + st_row[i], L - 1);
+            const long off = (long)ids[i] * cs_b + (long)(tok & bs_mask) * cs_t + head_off + st_ch[i] * 8;
+            kr[i] = *reinterpret_cast<const u32x4_t*>(k_cache + off);
+            vr[i] = *reinterpret_cast<const u32x4_t*>(v_cache + off);
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x4_t acc_o[NDB];
+#pragma unroll
+    for (int n = 0; n < NDB; ++n) acc_o[n] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    int tile = t0 + w;
+    u32x4_t kreg[ITER], vreg[ITER];
+    int ids_next[ITER];
+    if (tile < t1) {
+        int ids[ITER];
+        load_block_ids(tile, ids);
+        issue_loads(tile, ids, kreg, vreg);
+        if (tile + kWaves < t1) load_block_ids(tile + kWaves, ids_next);
+    }
+
+    for (; tile < t1; tile += kWaves) {
+        // registers -> wave-private LDS image (swizzled); same-wave DS ops stay in order
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int o = tile_off<CPR>(st_row[i], st_ch[i]);
+            *reinterpret_cast<u32x4_t*>(k_lds + o) = kreg[i];
+            *reinterpret_cast<u32x4_t*>(v_lds + o) = vreg[i];
+        }
+        if (tile + kWaves < t1) {
+            issue_loads(tile + kWaves, ids_next, kreg, vreg);
+            if (tile + 2 * kWaves < t1) load_block_ids(tile + 2 * kWaves, ids_next);
+        }
+
+        // ---- S^T[token][head] = K . Q^T : two 16-token sub-tiles
+        f32x4_t s_acc[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            s_acc[sub] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const u32x4_t kv = *reinterpret_cast<const u32x4_t*>(
+                    k_lds + tile_off<CPR>(16 * sub + c16, 4 * s + q4));
+                s_acc[sub] = DT::mfma16(__builtin_bit_cast(vec8, kv), qfrag[s], s_acc[sub]);
+            }
+        }
+        // lane (c16, q4) holds tokens 16 sub + 4 q4 + r of query head c16
+        float p[8];
+        float m_tile = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int tok = tile * kTile + 16 * sub + 4 * q4 + r;
+                const float v = tok < L ? s_acc[sub][r] * scale_log2 : -INFINITY;
+                p[4 * sub + r] = v;
+                m_tile = fmaxf(m_tile, v);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 16, 64));
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+        const float m_new = fmaxf(m_run, m_tile);          // finite: the tile has >= 1 token
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            p[j] = __builtin_amdgcn_exp2f(p[j] - m_new);
+            psum += p[j];
+        }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+        // P^T as B operand: k-slot j <-> token (j < 4 ? 4 q4 + j : 16 + 4 q4 + j - 4)
+        const vec8 pfrag = __builtin_bit_cast(vec8, pack8<CODE>(p));
+
+        // ---- O^T[d][head] += V^T . P^T
+        const int tr_row = 4 * q4 + (c16 >> 2);
+        const int tr_sub = (c16 & 1) * 8;
+#pragma unroll
+        for (int n = 0; n < NDB; ++n) {
+            const int ch = 2 * n + ((c16 & 3) >> 1);
+            const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(tr_row, ch) + tr_sub);
+            const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(16 + tr_row, ch) + tr_sub);
+            const s16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc_o[n] *= alpha;
+            acc_o[n] = DT::mfma16(__builtin_bit_cast(vec8, a), pfrag, acc_o[n]);
+        }
+    }
+
+    // ---- merge the 4 waves through LDS (each wave reuses its own staging region)
+    l_run += __shfl_xor(l_run, 16, 64);
+    l_run += __shfl_xor(l_run, 32, 64);
+    float* wbuf = reinterpret_cast<float*>(smem + w * WAVE_LDS);
+    if (q4 == 0) { wbuf[c16] = m_run; wbuf[16 + c16] = l_run; }
+#pragma unroll
+    for (int n = 0; n < NDB; ++n)
+        *reinterpret_cast<f32x4_t*>(wbuf + 32 + c16 * ACC_LD + 16 * n + 4 * q4) = acc_o[n];
+    __syncthreads();
+
+    for (int e = threadIdx.x; e < 16 * D; e += 256) {
+        const int c = e / D, d = e - c * D;
+        if (c >= nheads) continue;
+        float M = -INFINITY;
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww)
+            M = fmaxf(M, reinterpret_cast<const float*>(smem + ww * WAVE_LDS)[c]);
+        float o = 0.f, l = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < kWaves; ++ww) {
+            const float* wb = reinterpret_cast<const float*>(smem + ww * WAVE_LDS);
+            const float f = (wb[c] == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(wb[c] - M);
+            o += wb[32 + c * ACC_LD + d] * f;
+            l += wb[16 + c] * f;
+        }
+        const int head = head0 + c;
+        if (nsplit == 1) {
+            const float r = l > 0.f ? o / l : 0.f;
+            out[b * o_stride_b + head * o_stride_h + d] = DT::from_float(r);
+        } else {
+            const long pi = ((long)b * Hq + head) * nsplit + split;
+            part_acc[pi * D + d] = o;
+            if (d == 0) { part_ml[pi * 2] = M; part_ml[pi * 2 + 1] = l; }
+        }
+    }
+}
+
+// Merge the context splits: grid (Hq, B), D threads.
+template <int CODE, int D>
+__global__ void decode_reduce_kernel(const float* __restrict__ part_acc,
+                                     const float* __restrict__ part_ml,
+                                     uint16_t* __restrict__ out, long o_stride_b,
+                                     long o_stride_h, int Hq, int nsplit) {
+    const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
+    const long base = ((long)b * Hq + head) * nsplit;
+    float M = -INFINITY;
+    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(base + s) * 2]);
+    float o = 0.f, l = 0.f;
+    for (int s = 0; s < nsplit; ++s) {
+        const float ms = part_ml[(base + s) * 2];
+        const float f = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ms - M);
+        o += part_acc[(base + s) * D + d] * f;
+        l += part_ml[(base + s) * 2 + 1] * f;
+    }
+    out[b * o_stride_b + head * o_stride_h + d] = DType<CODE>::from_float(l > 0.f ? o / l : 0.f);
+}
+
+template <int CODE, int D>
+int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void* vc, long csb,
+                  long cst, long csh, const int* bt, int bt_stride, const int* ctx, void* out,
+                  long osb, long osh, float* part_acc, float* part_ml, float scale, int B, int Hq,
+                  int Hkv, int block_size, int nsplit, hipStream_t st) {
+    int bs_log2 = 0;
+    while ((1 << bs_log2) < block_size) ++bs_log2;
+    const int G = Hq / Hkv;
+    const int ngrp = (G + 15) / 16;
+    dim3 grid(nsplit, Hkv * ngrp, B);
+    const size_t lds = (size_t)kWaves * 2 * kTile * D * 2;
+    paged_decode_kernel<CODE, D><<<grid, 256, lds, st>>>(
+        (const uint16_t*)q, qsb, qsh, (const uint16_t*)kc, (const uint16_t*)vc, csb, cst, csh, bt,
+        bt_stride, ctx, (uint16_t*)out, osb, osh, part_acc, part_ml, scale * kLog2e, Hq, Hkv,
+        bs_log2, nsplit);
+    int rc = MVL_CHECK_LAUNCH();
+    if (rc != 0 || nsplit == 1) return rc;
+    decode_reduce_kernel<CODE, D><<<dim3(Hq, B), D, 0, st>>>(part_acc, part_ml, (uint16_t*)out,
+                                                            osb, osh, Hq, nsplit);
+    return MVL_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// q [B, Hq, D] (strides in elements), caches addressed by (block, token, kv head) strides,
+// block_size a power of two, part_* workspaces needed only when nsplit > 1:
+// part_acc [B*Hq*nsplit*D] fp32, part_ml [B*Hq*nsplit*2] fp32.
+extern "C" int mvl_paged_attention_decode(
+        const void* q, long q_stride_b, long q_stride_h, const void* k_cache, const void* v_cache,
+        long cs_b, long cs_t, long cs_h, const int* block_tables, int bt_stride,
+        const int* context_lens, void* out, long o_stride_b, long o_stride_h, float* part_acc,
+        float* part_ml, float scale, int B, int Hq, int Hkv, int D, int block_size, int nsplit,
+        int dtype, void* stream) {
+    if (B == 0) return 0;
+    if ((D != 64 && D != 128) || Hq % Hkv != 0 || (block_size & (block_size - 1)) || nsplit < 1)
+        return -1;
+    if (nsplit > 1 && (part_acc == nullptr || part_ml == nullptr)) return -2;
+    auto st = (hipStream_t)stream;
+#define MVL_DEC(CODE, DD)                                                                       \
+    return launch_decode<CODE, DD>(q, q_stride_b, q_stride_h, k_cache, v_cache, cs_b, cs_t, cs_h, \
+                                   block_tables, bt_stride, context_lens, out, o_stride_b,     \
+                                   o_stride_h, part_acc, part_ml, scale, B, Hq, Hkv,           \
+                                   block_size, nsplit, st)
+    if (dtype == 0) { if (D == 128) MVL_DEC(0, 128); else MVL_DEC(0, 64); }
+    else            { if (D == 128) MVL_DEC(1, 128); else MVL_DEC(1, 64); }
+#undef MVL_DEC
+}

@@ -1,0 +1,317 @@
+// Flash-attention prefill for gfx950: causal, variable-length, GQA, with the keys/values
+// read either from packed [T, Hkv, D] tensors or from the paged KV cache through a block
+// table (q_len <= k_len, so a cached prefix or an earlier chunk of the same prompt is
+// attended exactly).
+//
+// The reference Triton kernel uses 32x32 tiles at D=128, visits every KV tile even above the
+// causal diagonal, and can only see the new tokens' K/V (reference:
+// src/myvllm/layers/attention.py:111-280).  Design here:
+//
+//  * workgroup = 4 waves x 32 query rows (128-row Q tile), KV tiles of 64 rows; Q lives in
+//    registers for the whole kernel, K/V tiles are staged global -> registers -> LDS with the
+//    global loads issued one tile ahead (they fly under the MFMA work of the current tile)
+//    and block-table entries two tiles ahead;
+//  * S^T = K . Q^T on MFMA 32x32x16, so a lane owns one query row: the softmax row
+//    reduction is in-register plus one exchange between the two lane halves, and the
+//    accumulator is already the B operand of O^T = V^T . P^T (no LDS round trip for P);
+//  * V^T fragments come from ds_read_b64_tr_b16; the LDS image is XOR-swizzled so that both
+//    the K row reads (ds_read_b128) and the transposed V reads are bank-conflict free;
+//  * only KV tiles at or below the causal diagonal are visited, a wave skips the MFMA work
+//    of tiles that lie entirely above its own 32 rows, and the mask is applied on diagonal
+//    tiles only;
+//  * the 1-D grid is remapped so that workgroups sharing an XCD (and its L2) walk the query
+//    heads of one KV head and adjacent Q tiles of one sequence, heaviest Q tiles first.
+#include "common.h"
+
+using namespace mvl;
+
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+namespace {
+
+constexpr int kBM = 128;           // query rows per workgroup
+constexpr int kBN = 64;            // kv rows per tile
+constexpr int kThreads = 256;
+
+struct PrefillArgs {
+    const uint16_t* q; long q_stride_t; long q_stride_h;
+    const uint16_t* k; const uint16_t* v;      // packed mode: [T, Hkv, D]; paged: caches
+    long k_stride_t, k_stride_h;               // packed: token / head strides; paged: cs_t / cs_h
+    long cs_b;                                 // paged: block stride
+    uint16_t* out; long o_stride_t; long o_stride_h;
+    const int* cu_q; const int* cu_k;          // [B+1]
+    const int* block_tables; int bt_stride; int bs_log2;
+    float scale_log2;
+    int B, Hq, Hkv, n_qtiles;
+    int total_wg;
+};
+
+template <int CODE, int D, bool PAGED>
+__global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs a) {
+    using DT = DType<CODE>;
+    using vec8 = typename DT::vec8;
+    constexpr int CPR = D / 8;
+    constexpr int KSTEPS = D / 16;             // 32x32x16 k-steps over the head dim
+    constexpr int NDB = D / 32;                // 32-wide blocks of the output head dim
+    constexpr int ITER = kBN * CPR / kThreads; // staging chunks per thread per tile
+    constexpr int TILE_BYTES = kBN * D * 2;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* k_lds = smem;
+    char* v_lds = smem + TILE_BYTES;
+
+    // ---- work decomposition: XCD-aware remap of the linear block id -----------------
+    int id = blockIdx.x;
+    {
+        const int n = a.total_wg;
+        const int q8 = n >> 3, r8 = n & 7, x = id & 7;
+        // blocks with equal (id % 8) share an XCD: give each XCD a contiguous range
+        id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (id >> 3);
+    }
+    const int G = a.Hq / a.Hkv;
+    const int g = id % G;              id /= G;
+    const int qti = id % a.n_qtiles;   id /= a.n_qtiles;
+    const int kvh = id % a.Hkv;
+    const int b = id / a.Hkv;
+    const int head = kvh * G + g;
+
+    const int q_start = a.cu_q[b], q_len = a.cu_q[b + 1] - q_start;
+    const int k_start = a.cu_k[b], k_len = a.cu_k[b + 1] - k_start;
+    const int qt = a.n_qtiles - 1 - qti;                 // heaviest tiles first
+    const int q0 = qt * kBM;
+    if (q0 >= q_len) return;                             // uniform for the workgroup
+    const int pos_off = k_len - q_len;                   // query i sits at key position i + off
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r32 = lane & 31;
+    const int hh = lane >> 5;
+
+    // ---- Q^T fragments: lane holds Q[row r32][16 s + 8 hh .. +7] ------------------------
+    const int my_q = q0 + 32 * w + r32;                  // query index within the sequence
+    const int my_q_c = min(my_q, q_len - 1);
+    vec8 qfrag[KSTEPS];
+    {
+        const uint16_t* qp = a.q + (long)(q_start + my_q_c) * a.q_stride_t + (long)head * a.q_stride_h;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s)
+            qfrag[s] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(qp + 16 * s + 8 * hh));
+    }
+    const int my_pos = my_q + pos_off;                   // last key this row may see
+    const int wave_min_pos = q0 + 32 * w + pos_off;
+    const int wave_max_pos = min(q0 + 32 * w + 31, q_len - 1) + pos_off;
+    const bool wave_live = q0 + 32 * w < q_len;
+
+    const int last_pos = min(q0 + kBM - 1, q_len - 1) + pos_off;
+    const int n_tiles = last_pos / kBN + 1;
+
+    // ---- staging coordinates -----------------------------------------------------------
+    int st_row[ITER], st_ch[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) {
+        const int c = i * kThreads + threadIdx.x;
+        st_row[i] = c / CPR;
+        st_ch[i] = c % CPR;
+    }
+    const int bs_mask = (1 << a.bs_log2) - 1;
+    const int* bt = PAGED ? a.block_tables + (long)b * a.bt_stride : nullptr;
+    const long head_off = (long)kvh * a.k_stride_h;
+
+    auto load_block_ids = [&](int t, int (&ids)[ITER]) {
+        if (PAGED) {
+#pragma unroll
+            for (int i = 0; i < ITER; ++i) {
+                const int tok = min(t * kBN + st_row[i], k_len - 1);
+                ids[i] = bt[tok >> a.bs_log2];
+            }
+        }
+    };
+    auto issue_loads = [&](int t, const int (&ids)[ITER], u32x4_t (&kr)[ITER], u32x4_t (&vr)[ITER]) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int tok = min(t * kBN + st_row[i], k_len - 1);
+            long off;
+            if (PAGED)
+                off = (long)ids[i] * a.cs_b + (long)(tok & bs_mask) * a.k_stride_t + head_off + st_ch[i] * 8;
+            else
+                off = (long)(k_start + tok) * a.k_stride_t + head_off + st_ch[i] * 8;
+            kr[i] = *reinterpret_cast<const u32x4_t*>(a.k + off);
+            vr[i] = *reinterpret_cast<const u32x4_t*>(a.v + off);
+        }
+    };
+    auto write_lds = [&](const u32x4_t (&kr)[ITER], const u32x4_t (&vr)[ITER]) {
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            const int o = tile_off<CPR>(st_row[i], st_ch[i]);
+            *reinterpret_cast<u32x4_t*>(k_lds + o) = kr[i];
+            *reinterpret_cast<u32x4_t*>(v_lds + o) = vr[i];
+        }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16_t acc_o[NDB];
+#pragma unroll
+    for (int n = 0; n < NDB; ++n)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc_o[n][e] = 0.f;
+
+    u32x4_t kreg[ITER], vreg[ITER];
+    int ids_next[ITER];
+    {
+        int ids[ITER];
+        load_block_ids(0, ids);
+        issue_loads(0, ids, kreg, vreg);
+        if (n_tiles > 1) load_block_ids(1, ids_next);
+    }
+    write_lds(kreg, vreg);
+    __syncthreads();
+
+    // transposed-read lane constants: 16-lane group gq = lane >> 4; (gq & 1) picks the
+    // 16-column half of a 32-wide d block, hh = gq >> 1 picks the key rows
+    const int i16 = lane & 15;
+    const int tr_row0 = 4 * hh + (i16 >> 2);
+    const int tr_chunk0 = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
+    const int tr_sub = (i16 & 1) * 8;
+
+    for (int t = 0; t < n_tiles; ++t) {
+        if (t + 1 < n_tiles) {
+            issue_loads(t + 1, ids_next, kreg, vreg);
+            if (t + 2 < n_tiles) load_block_ids(t + 2, ids_next);
+        }
+        const int kv0 = t * kBN;
+        if (wave_live && kv0 <= wave_max_pos) {
+            // ---- S^T[kv][q] = K . Q^T : two 32-row sub-tiles --------------------------
+            f32x16_t s_acc[2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) s_acc[sub][e] = 0.f;
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    const u32x4_t kv = *reinterpret_cast<const u32x4_t*>(
+                        k_lds + tile_off<CPR>(32 * sub + r32, 2 * s + hh));
+                    s_acc[sub] = DT::mfma32(__builtin_bit_cast(vec8, kv), qfrag[s], s_acc[sub]);
+                }
+            }
+            // lane (r32, hh) holds, for query row r32, keys kv0 + 32 sub + (e&3) + 8 (e>>2) + 4 hh
+            const bool need_mask = kv0 + kBN - 1 > wave_min_pos;
+            float m_tile = -INFINITY;
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float v = s_acc[sub][e] * a.scale_log2;
+                    if (need_mask) {
+                        const int kv = kv0 + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                        if (kv > my_pos) v = -INFINITY;
+                    }
+                    s_acc[sub][e] = v;
+                    m_tile = fmaxf(m_tile, v);
+                }
+            m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+            const float m_new = fmaxf(m_run, m_tile);
+            // a row past q_len (clamped duplicate) or a fully masked row keeps m = -inf:
+            // use a finite stand-in so that exp2 sees (-inf) - finite = -inf -> 0
+            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
+            float psum = 0.f;
+            vec8 pfrag[2][2];
+#pragma unroll
+            for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    float p[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        p[j] = __builtin_amdgcn_exp2f(s_acc[sub][8 * s + j] - m_use);
+                        psum += p[j];
+                    }
+                    pfrag[sub][s] = __builtin_bit_cast(vec8, pack8<CODE>(p));
+                }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+
+            // ---- O^T[d][q] += V^T . P^T ---------------------------------------------
+#pragma unroll
+            for (int n = 0; n < NDB; ++n) {
+                acc_o[n] *= alpha;
+#pragma unroll
+                for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        // k-slot j of lane half hh <-> key 32 sub + 16 s + 8 (j>>2) + 4 hh + (j&3)
+                        const int row = 32 * sub + 16 * s + tr_row0;
+                        const int ch = 4 * n + tr_chunk0;
+                        const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(row, ch) + tr_sub);
+                        const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(row + 8, ch) + tr_sub);
+                        const s16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc_o[n] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[sub][s], acc_o[n]);
+                    }
+            }
+        }
+        if (t + 1 < n_tiles) {
+            __syncthreads();                 // every wave is done reading tile t
+            write_lds(kreg, vreg);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: O[q][d] = O^T / l --------------------------------------------------
+    l_run += __shfl_xor(l_run, 32, 64);
+    if (my_q < q_len) {
+        const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
+        uint16_t* op = a.out + (long)(q_start + my_q) * a.o_stride_t + (long)head * a.o_stride_h;
+#pragma unroll
+        for (int n = 0; n < NDB; ++n)
+#pragma unroll
+            for (int g8 = 0; g8 < 4; ++g8) {
+                // registers 4 g8 .. 4 g8 + 3 are d = 32 n + 8 g8 + 4 hh + (0..3)
+                u32x2_t o;
+                o[0] = pack2<CODE>(acc_o[n][4 * g8 + 0] * inv, acc_o[n][4 * g8 + 1] * inv);
+                o[1] = pack2<CODE>(acc_o[n][4 * g8 + 2] * inv, acc_o[n][4 * g8 + 3] * inv);
+                *reinterpret_cast<u32x2_t*>(op + 32 * n + 8 * g8 + 4 * hh) = o;
+            }
+    }
+}
+
+template <int CODE, int D, bool PAGED>
+int launch_prefill(PrefillArgs a, hipStream_t st) {
+    const size_t lds = 2 * (size_t)kBN * D * 2;
+    flash_prefill_kernel<CODE, D, PAGED><<<a.total_wg, kThreads, lds, st>>>(a);
+    return MVL_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// paged == 0: k/v are packed [T, Hkv, D] tensors (token stride k_stride_t, head stride
+// k_stride_h), cu_k may equal cu_q.  paged == 1: k/v are caches addressed by
+// (block stride cs_b, token stride k_stride_t, head stride k_stride_h) through block_tables.
+extern "C" int mvl_flash_attention_prefill(
+        const void* q, long q_stride_t, long q_stride_h, const void* k, const void* v,
+        long k_stride_t, long k_stride_h, long cs_b, void* out, long o_stride_t, long o_stride_h,
+        const int* cu_q, const int* cu_k, const int* block_tables, int bt_stride, int block_size,
+        float scale, int B, int Hq, int Hkv, int D, int max_q_len, int paged, int dtype,
+        void* stream) {
+    if (B == 0 || max_q_len <= 0) return 0;
+    if ((D != 64 && D != 128) || Hq % Hkv != 0) return -1;
+    if (paged && (block_size & (block_size - 1))) return -1;
+    PrefillArgs a;
+    a.q = (const uint16_t*)q; a.q_stride_t = q_stride_t; a.q_stride_h = q_stride_h;
+    a.k = (const uint16_t*)k; a.v = (const uint16_t*)v;
+    a.k_stride_t = k_stride_t; a.k_stride_h = k_stride_h; a.cs_b = cs_b;
+    a.out = (uint16_t*)out; a.o_stride_t = o_stride_t; a.o_stride_h = o_stride_h;
+    a.cu_q = cu_q; a.cu_k = cu_k; a.block_tables = block_tables; a.bt_stride = bt_stride;
+    int l2 = 0;
+    while (paged && (1 << l2) < block_size) ++l2;
+    a.bs_log2 = l2;
+    a.scale_log2 = scale * kLog2e;
+    a.B = B; a.Hq = Hq; a.Hkv = Hkv;
+    a.n_qtiles = (max_q_len + kBM - 1) / kBM;
+    a.total_wg = B * Hq * a.n_qtiles;
+    auto st = (hipStream_t)stream;
+#define MVL_PRE(CODE, DD)                                                         \
+    return paged ? launch_prefill<CODE, DD, true>(a, st) : launch_prefill<CODE, DD, false>(a, st)
+    if (dtype == 0) { if (D == 128) MVL_PRE(0, 128); else MVL_PRE(0, 64); }
+    else            { if (D == 128) MVL_PRE(1, 128); else MVL_PRE(1, 64); }
+#undef MVL_PRE
+}

@@ -1,0 +1,286 @@
+"""ctypes bindings for the gfx950 kernel library (``_hip_kernels.so``).
+
+Every launcher takes raw device pointers, element strides and the current HIP stream, so a
+call made while a hipGraph is being captured on that stream becomes a graph node.  The
+library is built in-tree by ``minivllm_amd.build``; importing this module on a machine with a
+GPU but without the built library raises (there is no silent PyTorch fallback for GPU
+tensors).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                         "_hip_kernels.so")
+if not os.path.exists(_LIB_PATH):
+    raise ImportError(
+        f"{_LIB_PATH} is missing: build the HIP kernels first with "
+        f"`python -m minivllm_amd.build` (needs hipcc; cross-compiles for gfx950 without a GPU)")
+_lib = ctypes.CDLL(_LIB_PATH)
+
+_c_long, _c_int, _c_float, _c_void, _c_u64 = (ctypes.c_long, ctypes.c_int, ctypes.c_float,
+                                               ctypes.c_void_p, ctypes.c_uint64)
+
+
+def _sig(name, *argtypes):
+    f = getattr(_lib, name)
+    f.argtypes = list(argtypes)
+    f.restype = ctypes.c_int
+    return f
+
+
+_rms = _sig("mvl_rms_norm", _c_void, _c_void, _c_void, _c_long, _c_int, _c_long, _c_long,
+            _c_float, _c_int, _c_void)
+_add_rms = _sig("mvl_add_rms_norm", _c_void, _c_void, _c_void, _c_void, _c_long, _c_int, _c_long,
+                _c_long, _c_long, _c_float, _c_int, _c_void)
+_silu = _sig("mvl_silu_and_mul", _c_void, _c_void, _c_long, _c_int, _c_long, _c_long, _c_int,
+             _c_void)
+_rope = _sig("mvl_qk_norm_rope_store", _c_void, _c_long, _c_void, _c_void, _c_void, _c_void,
+             _c_float, _c_long, _c_int, _c_int, _c_int, _c_void, _c_void, _c_long, _c_long,
+             _c_long, _c_int, _c_void, _c_int, _c_void)
+_store = _sig("mvl_store_kvcache", _c_void, _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
+              _c_long, _c_long, _c_int, _c_void, _c_long, _c_int, _c_int, _c_void)
+_sample = _sig("mvl_sample", _c_void, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void, _c_u64,
+               _c_void, _c_void, _c_void, _c_int, _c_void)
+_decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
+               _c_long, _c_long, _c_void, _c_int, _c_void, _c_void, _c_long, _c_long, _c_void,
+               _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void)
+_prefill = _sig("mvl_flash_attention_prefill", _c_void, _c_long, _c_long, _c_void, _c_void,
+                _c_long, _c_long, _c_long, _c_void, _c_long, _c_long, _c_void, _c_void, _c_void,
+                _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+                _c_void)
+
+_DT = {torch.bfloat16: 0, torch.float16: 1}
+
+
+def _dt(t: torch.Tensor) -> int:
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError(f"HIP kernels take bf16/fp16 tensors, got {t.dtype}")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(rc: int, name: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): bad shape/alignment for the kernel or "
+                           f"a HIP launch error")
+
+
+def _rows2d(x: torch.Tensor) -> Tuple[torch.Tensor, int, int]:
+    """View x as [rows, hidden] with unit inner stride; returns (x2d, rows, row_stride)."""
+    h = x.shape[-1]
+    x2 = x.reshape(-1, h)
+    if x2.stride(-1) != 1:
+        x2 = x2.contiguous()
+    return x2, x2.shape[0], (x2.stride(0) if x2.shape[0] > 1 else h)
+
+
+def _i32(t: torch.Tensor) -> torch.Tensor:
+    return t if t.dtype == torch.int32 else t.to(torch.int32)
+
+
+# --------------------------------------------------------------------- norms
+def rms_norm(x: torch.Tensor, weight: torch.Tensor, eps: float) -> torch.Tensor:
+    x2, rows, xs = _rows2d(x)
+    out = torch.empty((rows, x.shape[-1]), dtype=x.dtype, device=x.device)
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    _check(_rms(x2.data_ptr(), w.data_ptr(), out.data_ptr(), rows, x.shape[-1], xs, x.shape[-1],
+                eps, _dt(x), _stream()), "rms_norm")
+    return out.view(x.shape)
+
+
+def add_rms_norm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float):
+    """In place: ``residual <- x + residual`` and ``x <- norm(residual)``; returns (x, residual)."""
+    x2, rows, xs = _rows2d(x)
+    r2, _, rs = _rows2d(residual)
+    if x2.data_ptr() != x.data_ptr() or r2.data_ptr() != residual.data_ptr():
+        raise ValueError("add_rms_norm needs row-contiguous tensors (it updates them in place)")
+    w = weight if weight.dtype == x.dtype else weight.to(x.dtype)
+    _check(_add_rms(x2.data_ptr(), r2.data_ptr(), w.data_ptr(), x2.data_ptr(), rows, x.shape[-1],
+                    xs, rs, xs, eps, _dt(x), _stream()), "add_rms_norm")
+    return x, residual
+
+
+def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
+    x2, rows, xs = _rows2d(x)
+    inter = x.shape[-1] // 2
+    out = torch.empty((rows, inter), dtype=x.dtype, device=x.device)
+    _check(_silu(x2.data_ptr(), out.data_ptr(), rows, inter, xs, inter, _dt(x), _stream()),
+           "silu_and_mul")
+    return out.view(*x.shape[:-1], inter)
+
+
+# ---------------------------------------------------------------- rope / store
+def _cache_strides(cache: torch.Tensor):
+    """cache is logically [block, token, kv_head, d] with arbitrary physical order."""
+    if cache.stride(3) != 1:
+        raise ValueError("KV cache head_dim must be contiguous")
+    return cache.stride(0), cache.stride(1), cache.stride(2)
+
+
+def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torch.Tensor,
+                       q_weight: Optional[torch.Tensor], k_weight: Optional[torch.Tensor],
+                       eps: float, num_heads: int, num_kv_heads: int, head_dim: int,
+                       k_cache: Optional[torch.Tensor], v_cache: Optional[torch.Tensor],
+                       slot_mapping: Optional[torch.Tensor]):
+    """Works in place on ``qkv`` [T, (Hq+2Hkv)*D]; returns (q, k, v) views of it."""
+    assert qkv.dim() == 2 and qkv.stride(1) == 1
+    T = qkv.shape[0]
+    qs, ks = num_heads * head_dim, num_kv_heads * head_dim
+    assert qkv.shape[1] == qs + 2 * ks
+    if cos_sin.dtype != torch.float32:
+        raise TypeError("cos/sin table must be fp32")
+    positions = _i32(positions)
+    have_cache = k_cache is not None and slot_mapping is not None
+    if have_cache:
+        sb, st, sh = _cache_strides(k_cache)
+        assert _cache_strides(v_cache) == (sb, st, sh)
+        slot_mapping = _i32(slot_mapping)
+        bs = k_cache.shape[1]
+    else:
+        sb = st = sh = 0
+        bs = 1
+    qw = q_weight.data_ptr() if q_weight is not None else None
+    kw = k_weight.data_ptr() if k_weight is not None else None
+    if q_weight is not None:
+        assert q_weight.dtype == qkv.dtype and k_weight.dtype == qkv.dtype
+    _check(_rope(qkv.data_ptr(), qkv.stride(0), positions.data_ptr(), cos_sin.data_ptr(), qw, kw,
+                 eps, T, num_heads, num_kv_heads, head_dim,
+                 k_cache.data_ptr() if have_cache else None,
+                 v_cache.data_ptr() if have_cache else None, sb, st, sh, bs,
+                 slot_mapping.data_ptr() if have_cache else None, _dt(qkv), _stream()),
+           "qk_norm_rope_store")
+    q = qkv[:, :qs].view(T, num_heads, head_dim)
+    k = qkv[:, qs:qs + ks].view(T, num_kv_heads, head_dim)
+    v = qkv[:, qs + ks:].view(T, num_kv_heads, head_dim)
+    return q, k, v
+
+
+def store_kvcache(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor,
+                  v_cache: torch.Tensor, slot_mapping: torch.Tensor) -> None:
+    T, hkv, d = key.shape
+    assert key.stride(2) == 1 and key.stride(1) == d and value.stride(2) == 1 and value.stride(1) == d
+    sb, st, sh = _cache_strides(k_cache)
+    assert _cache_strides(v_cache) == (sb, st, sh)
+    assert key.dtype == k_cache.dtype
+    slot_mapping = _i32(slot_mapping)
+    _check(_store(key.data_ptr(), value.data_ptr(), key.stride(0), value.stride(0),
+                  k_cache.data_ptr(), v_cache.data_ptr(), sb, st, sh, k_cache.shape[1],
+                  slot_mapping.data_ptr(), T, hkv, d, _stream()), "store_kvcache")
+
+
+# ------------------------------------------------------------------ attention
+def _q_strides(q: torch.Tensor):
+    assert q.dim() == 3 and q.stride(2) == 1, "q must be [T, H, D] with contiguous D"
+    return q.stride(0), q.stride(1)
+
+
+def flash_attention_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                            cu_seqlens: torch.Tensor, scale: float,
+                            max_seqlen: Optional[int] = None) -> torch.Tensor:
+    T, hq, d = q.shape
+    hkv = k.shape[1]
+    cu = _i32(cu_seqlens)
+    if max_seqlen is None:
+        max_seqlen = int((cu[1:] - cu[:-1]).max().item())
+    qs_t, qs_h = _q_strides(q)
+    ks_t, ks_h = _q_strides(k)
+    assert _q_strides(v) == (ks_t, ks_h), "k and v must share strides"
+    out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    _check(_prefill(q.data_ptr(), qs_t, qs_h, k.data_ptr(), v.data_ptr(), ks_t, ks_h, 0,
+                    out.data_ptr(), out.stride(0), out.stride(1), cu.data_ptr(), cu.data_ptr(),
+                    None, 0, 1, scale, cu.numel() - 1, hq, hkv, d, max_seqlen, 0, _dt(q),
+                    _stream()), "flash_attention_prefill")
+    return out
+
+
+def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                            cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
+                            block_tables: torch.Tensor, scale: float,
+                            max_seqlen_q: Optional[int] = None) -> torch.Tensor:
+    T, hq, d = q.shape
+    hkv = k_cache.shape[2]
+    cq, ck, bt = _i32(cu_seqlens_q), _i32(cu_seqlens_k), _i32(block_tables)
+    if max_seqlen_q is None:
+        max_seqlen_q = int((cq[1:] - cq[:-1]).max().item())
+    qs_t, qs_h = _q_strides(q)
+    sb, st, sh = _cache_strides(k_cache)
+    assert _cache_strides(v_cache) == (sb, st, sh)
+    assert bt.stride(1) == 1
+    out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    _check(_prefill(q.data_ptr(), qs_t, qs_h, k_cache.data_ptr(), v_cache.data_ptr(), st, sh, sb,
+                    out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
+                    bt.data_ptr(), bt.stride(0), k_cache.shape[1], scale, cq.numel() - 1, hq, hkv,
+                    d, max_seqlen_q, 1, _dt(q), _stream()), "paged_attention_prefill")
+    return out
+
+
+def decode_num_splits(batch: int, num_kv_heads: int, max_context_len: Optional[int]) -> int:
+    """Context splits so that ~2 workgroups per CU exist even at batch 1; never more splits
+    than 128-token chunks of the longest context."""
+    wgs = max(batch * num_kv_heads, 1)
+    n = max(1, min(32, 512 // wgs))
+    if max_context_len is not None:
+        n = max(1, min(n, (max_context_len + 127) // 128))
+    return n
+
+
+def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
+                           block_tables: torch.Tensor, context_lens: torch.Tensor, scale: float,
+                           max_context_len: Optional[int] = None,
+                           num_splits: Optional[int] = None) -> torch.Tensor:
+    B, hq, d = q.shape
+    hkv = k_cache.shape[2]
+    bt, ctx = _i32(block_tables), _i32(context_lens)
+    qs_b, qs_h = _q_strides(q)
+    sb, st, sh = _cache_strides(k_cache)
+    assert _cache_strides(v_cache) == (sb, st, sh)
+    assert bt.stride(1) == 1
+    ns = num_splits or decode_num_splits(B, hkv, max_context_len)
+    out = torch.empty((B, hq, d), dtype=q.dtype, device=q.device)
+    if ns > 1:
+        part_acc = torch.empty(B * hq * ns * d, dtype=torch.float32, device=q.device)
+        part_ml = torch.empty(B * hq * ns * 2, dtype=torch.float32, device=q.device)
+        pa, pm = part_acc.data_ptr(), part_ml.data_ptr()
+    else:
+        pa = pm = None
+    _check(_decode(q.data_ptr(), qs_b, qs_h, k_cache.data_ptr(), v_cache.data_ptr(), sb, st, sh,
+                   bt.data_ptr(), bt.stride(0), ctx.data_ptr(), out.data_ptr(), out.stride(0),
+                   out.stride(1), pa, pm, scale, B, hq, hkv, d, k_cache.shape[1], ns, _dt(q),
+                   _stream()), "paged_attention_decode")
+    return out
+
+
+# -------------------------------------------------------------------- sampler
+_LOGIT_DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
+def sample_local(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, step,
+                 vocab_offset: int = 0, valid_vocab: Optional[int] = None):
+    """Best (score, global index) per row over this rank's vocabulary shard.
+    ``step`` is an int or a 1-element int32 device tensor (graph-safe)."""
+    assert logits.dim() == 2 and logits.stride(1) == 1
+    B, V = logits.shape
+    if valid_vocab is None:
+        valid_vocab = vocab_offset + V
+    if not torch.is_tensor(step):
+        step = torch.tensor([int(step) & 0x7fffffff], dtype=torch.int32, device=logits.device)
+    temps = temperatures if temperatures.dtype == torch.float32 else temperatures.float()
+    vals = torch.empty(B, dtype=torch.float32, device=logits.device)
+    idx = torch.empty(B, dtype=torch.int32, device=logits.device)
+    _check(_sample(logits.data_ptr(), logits.stride(0), B, V, vocab_offset, valid_vocab,
+                   temps.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, step.data_ptr(), vals.data_ptr(),
+                   idx.data_ptr(), _LOGIT_DT[logits.dtype], _stream()), "sample")
+    return vals, idx
+
+
+def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int = 0, step=0) -> torch.Tensor:
+    return sample_local(logits, temperatures, seed, step)[1].to(torch.int64)

@@ -1,0 +1,293 @@
+"""Numerics of every HIP kernel against the plain-PyTorch fp32 oracle of the same op
+(``minivllm_amd.ops.torch_ref``).  Needs a real MI355X."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from minivllm_amd.ops import hip as h      # raises loudly when the .so is missing
+    return h
+
+
+from minivllm_amd.ops import torch_ref as ref  # noqa: E402
+
+DEV = "cuda"
+TOL = {torch.bfloat16: dict(atol=2e-2, rtol=2e-2), torch.float16: dict(atol=4e-3, rtol=4e-3)}
+
+
+def close(a, b, dtype, scale=1.0):
+    t = TOL[dtype]
+    torch.testing.assert_close(a.float(), b.float(), atol=t["atol"] * scale, rtol=t["rtol"])
+
+
+# ------------------------------------------------------------------ elementwise
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,hidden", [(1, 1024), (7, 4096), (33, 5120), (5, 128), (3, 8192), (2, 64)])
+def test_rms_norm(hip, dtype, rows, hidden):
+    torch.manual_seed(0)
+    x = torch.randn(rows, hidden, device=DEV, dtype=dtype)
+    w = (1 + 0.1 * torch.randn(hidden, device=DEV)).to(dtype)
+    close(hip.rms_norm(x, w, 1e-6), ref.rms_norm(x, w, 1e-6), dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,hidden", [(1, 1024), (19, 4096), (4, 5120)])
+def test_add_rms_norm(hip, dtype, rows, hidden):
+    torch.manual_seed(1)
+    x = torch.randn(rows, hidden, device=DEV, dtype=dtype)
+    r = torch.randn(rows, hidden, device=DEV, dtype=dtype)
+    w = (1 + 0.1 * torch.randn(hidden, device=DEV)).to(dtype)
+    want_o, want_r = ref.add_rms_norm(x, r, w, 1e-6)
+    got_o, got_r = hip.add_rms_norm(x.clone(), r.clone(), w, 1e-6)
+    torch.testing.assert_close(got_r.float(), want_r.float(), atol=0, rtol=0)
+    close(got_o, want_o, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("rows,inter", [(1, 3072), (17, 12288), (400, 800), (3, 8)])
+def test_silu_and_mul(hip, dtype, rows, inter):
+    torch.manual_seed(2)
+    x = torch.randn(rows, 2 * inter, device=DEV, dtype=dtype)
+    close(hip.silu_and_mul(x), ref.silu_and_mul(x), dtype)
+
+
+def _logical_cache(nb, bs, hkv, d, dtype, head_major=True):
+    """[nb, bs, hkv, d] logical view; physical order head-major like the engine's."""
+    if head_major:
+        return torch.zeros(nb, hkv, bs, d, device=DEV, dtype=dtype).permute(0, 2, 1, 3)
+    return torch.zeros(nb, bs, hkv, d, device=DEV, dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [64, 128])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_qk_norm_rope_store(hip, dtype, d, with_norm):
+    torch.manual_seed(3)
+    T, hq, hkv, bs, nb = 37, 8, 2, 16, 8
+    qkv = torch.randn(T, (hq + 2 * hkv) * d, device=DEV, dtype=dtype)
+    pos = torch.randint(0, 500, (T,), device=DEV, dtype=torch.int32)
+    cs = ref.build_cos_sin_cache(d, 512, 10000.0, DEV)
+    qw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype) if with_norm else None
+    kw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype) if with_norm else None
+    slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
+    slots[5] = -1
+    kc_r, vc_r = _logical_cache(nb, bs, hkv, d, dtype), _logical_cache(nb, bs, hkv, d, dtype)
+    kc_h, vc_h = _logical_cache(nb, bs, hkv, d, dtype), _logical_cache(nb, bs, hkv, d, dtype)
+    q_r, k_r, v_r = ref.qk_norm_rope_store(qkv.clone(), pos, cs, qw, kw, 1e-6, hq, hkv, d, kc_r, vc_r, slots)
+    q_h, k_h, v_h = hip.qk_norm_rope_store(qkv.clone(), pos, cs, qw, kw, 1e-6, hq, hkv, d, kc_h, vc_h, slots)
+    close(q_h, q_r, dtype, 2)
+    close(k_h, k_r, dtype, 2)
+    close(v_h, v_r, dtype)
+    close(kc_h, kc_r, dtype, 2)
+    close(vc_h, vc_r, dtype)
+
+
+@pytest.mark.parametrize("head_major", [True, False])
+def test_store_kvcache(hip, head_major):
+    torch.manual_seed(4)
+    dtype = torch.bfloat16
+    T, hkv, d, bs, nb = 50, 4, 128, 16, 6
+    k = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    slots = torch.randperm(nb * bs, device=DEV)[:T]          # int64 like the reference passes
+    slots[0] = -1
+    kc_r, vc_r = _logical_cache(nb, bs, hkv, d, dtype, head_major), _logical_cache(nb, bs, hkv, d, dtype, head_major)
+    kc_h, vc_h = _logical_cache(nb, bs, hkv, d, dtype, head_major), _logical_cache(nb, bs, hkv, d, dtype, head_major)
+    ref.store_kvcache(k, v, kc_r, vc_r, slots)
+    hip.store_kvcache(k, v, kc_h, vc_h, slots)
+    torch.testing.assert_close(kc_h, kc_r, atol=0, rtol=0)
+    torch.testing.assert_close(vc_h, vc_r, atol=0, rtol=0)
+
+
+# --------------------------------------------------------------------- sampler
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_sampler_greedy(hip, dtype):
+    torch.manual_seed(5)
+    logits = torch.randn(9, 151936, device=DEV, dtype=dtype)
+    t = torch.zeros(9, device=DEV)
+    got = hip.sample(logits, t, seed=1, step=3)
+    assert got.tolist() == logits.float().argmax(-1).tolist()
+
+
+def test_sampler_distribution(hip):
+    """Empirical frequencies of the exponential-race sampler match softmax(logits / T)."""
+    torch.manual_seed(6)
+    V, n, T = 16, 20000, 0.7
+    base = torch.randn(V, device=DEV)
+    logits = base.repeat(n, 1).to(torch.float32)
+    temps = torch.full((n,), T, device=DEV)
+    got = hip.sample(logits, temps, seed=123, step=7)
+    freq = torch.bincount(got, minlength=V).float() / n
+    want = torch.softmax(base / T, -1)
+    assert (freq - want).abs().max().item() < 0.015
+    # a different step gives a different draw, same step the same draw
+    again = hip.sample(logits, temps, seed=123, step=7)
+    other = hip.sample(logits, temps, seed=123, step=8)
+    assert torch.equal(got, again) and not torch.equal(got, other)
+
+
+def test_sampler_vocab_shards_agree(hip):
+    """Sampling shard-wise and combining (value, index) pairs equals sampling the full row."""
+    torch.manual_seed(7)
+    B, V = 6, 4096
+    logits = torch.randn(B, V, device=DEV, dtype=torch.bfloat16)
+    temps = torch.tensor([0.0, 0.5, 1.0, 0.0, 2.0, 0.8], device=DEV)
+    full_v, full_i = hip.sample_local(logits, temps, 9, 4)
+    parts = [hip.sample_local(logits[:, s:s + 1024].contiguous(), temps, 9, 4, vocab_offset=s,
+                              valid_vocab=V) for s in range(0, V, 1024)]
+    vals = torch.stack([p[0] for p in parts])
+    idx = torch.stack([p[1] for p in parts])
+    best = vals.argmax(0)
+    assert torch.equal(idx.gather(0, best[None]).squeeze(0), full_i)
+
+
+# ------------------------------------------------------------------- attention
+def _fill_paged(k, v, lens, bs, hkv, d, dtype, head_major=True, shuffle=True):
+    """Scatter packed k/v [sum(lens), hkv, d] into a paged cache; returns caches + tables."""
+    nblk = [(L + bs - 1) // bs for L in lens]
+    total = sum(nblk) + 3
+    perm = torch.randperm(total) if shuffle else torch.arange(total)
+    kc, vc = _logical_cache(total, bs, hkv, d, dtype, head_major), _logical_cache(total, bs, hkv, d, dtype, head_major)
+    tables = torch.full((len(lens), max(nblk)), -1, dtype=torch.int32)
+    off = used = 0
+    for i, L in enumerate(lens):
+        ids = perm[used:used + nblk[i]]
+        used += nblk[i]
+        tables[i, :nblk[i]] = ids.to(torch.int32)
+        for j, blk in enumerate(ids.tolist()):
+            n = min(bs, L - j * bs)
+            kc[blk, :n] = k[off + j * bs: off + j * bs + n]
+            vc[blk, :n] = v[off + j * bs: off + j * bs + n]
+        off += L
+    return kc, vc, tables.to(DEV)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (16, 8, 128), (8, 1, 128), (16, 8, 64), (4, 4, 128)])
+@pytest.mark.parametrize("bs", [16, 256])
+def test_paged_decode(hip, dtype, hq, hkv, d, bs):
+    torch.manual_seed(8)
+    lens = [1, 31, 32, 33, 260, 1000, 77]
+    B = len(lens)
+    k = torch.randn(sum(lens), hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(sum(lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(k, v, lens, bs, hkv, d, dtype)
+    q = torch.randn(B, hq, d, device=DEV, dtype=dtype)
+    ctx = torch.tensor(lens, device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    want = ref.paged_attention_decode(q, kc, vc, tables, ctx, scale)
+    for ns in (1, 3, 8):
+        got = hip.paged_attention_decode(q, kc, vc, tables, ctx, scale, num_splits=ns)
+        close(got, want, dtype)
+    got = hip.paged_attention_decode(q, kc, vc, tables, ctx, scale, max_context_len=max(lens))
+    close(got, want, dtype)
+
+
+def test_paged_decode_reference_layout_and_padding(hip):
+    """Token-major cache (the layout the reference benchmark builds), strided q, and rows with
+    context 0 (graph padding) which must come out as zeros without touching the table."""
+    torch.manual_seed(9)
+    dtype, hq, hkv, d, bs = torch.float16, 32, 8, 128, 16
+    lens = [60, 512, 0, 5]
+    fill = [60, 512, 1, 5]
+    k = torch.randn(sum(fill), hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(sum(fill), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(k, v, fill, bs, hkv, d, dtype, head_major=False)
+    tables[2] = -1
+    qkv = torch.randn(len(lens), (hq + 2 * hkv) * d, device=DEV, dtype=dtype)
+    q = qkv[:, :hq * d].view(len(lens), hq, d)
+    ctx = torch.tensor(lens, device=DEV, dtype=torch.int32)
+    want = ref.paged_attention_decode(q, kc, vc, tables, ctx, 0.09)
+    got = hip.paged_attention_decode(q, kc, vc, tables, ctx, 0.09, num_splits=2)
+    close(got, want, dtype)
+    assert got[2].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (4, 2, 128), (8, 1, 128), (16, 8, 64)])
+def test_flash_prefill_packed(hip, dtype, hq, hkv, d):
+    torch.manual_seed(10)
+    lens = [1, 60, 64, 129, 300, 17]
+    T = sum(lens)
+    q = torch.randn(T, hq, d, device=DEV, dtype=dtype)
+    k = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    want = ref.flash_attention_prefill(q, k, v, cu, scale)
+    got = hip.flash_attention_prefill(q, k, v, cu, scale)
+    close(got, want, dtype)
+
+
+def test_flash_prefill_strided_qkv(hip):
+    """q/k/v as column slices of one fused projection output (how the model calls it)."""
+    torch.manual_seed(11)
+    dtype, hq, hkv, d = torch.bfloat16, 16, 8, 128
+    lens = [200, 45]
+    T = sum(lens)
+    qkv = torch.randn(T, (hq + 2 * hkv) * d, device=DEV, dtype=dtype)
+    q = qkv[:, :hq * d].view(T, hq, d)
+    k = qkv[:, hq * d:(hq + hkv) * d].view(T, hkv, d)
+    v = qkv[:, (hq + hkv) * d:].view(T, hkv, d)
+    cu = torch.tensor([0, 200, 245], device=DEV, dtype=torch.int32)
+    want = ref.flash_attention_prefill(q, k, v, cu, 0.088)
+    got = hip.flash_attention_prefill(q, k, v, cu, 0.088, max_seqlen=200)
+    close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("bs", [16, 256])
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (16, 8, 64)])
+def test_paged_prefill_with_prefix(hip, dtype, bs, hq, hkv, d):
+    """q_len <= k_len: the new tokens attend to a cached prefix through the block table."""
+    torch.manual_seed(12)
+    k_lens = [300, 64, 513, 40, 256]
+    q_lens = [300, 1, 257, 40, 130]         # full, single token, chunk, full, partial
+    k = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(k, v, k_lens, bs, hkv, d, dtype)
+    q = torch.randn(sum(q_lens), hq, d, device=DEV, dtype=dtype)
+    cq = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    ck = torch.tensor([0] + list(torch.tensor(k_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    want = ref.paged_attention_prefill(q, kc, vc, cq, ck, tables, scale)
+    got = hip.paged_attention_prefill(q, kc, vc, cq, ck, tables, scale)
+    close(got, want, dtype)
+
+
+def test_flash_prefill_long_and_softmax_rescale(hip):
+    """4k tokens (many KV tiles) with a spiked key late in the sequence, which forces the
+    running-max rescale branch of the online softmax on rows that already accumulated."""
+    torch.manual_seed(13)
+    dtype, hq, hkv, d, T = torch.bfloat16, 8, 2, 128, 4096
+    q = torch.randn(T, hq, d, device=DEV, dtype=dtype)
+    k = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    k[3000] = 6.0 * q[3500, 0]               # row 3500 of head 0 (kv head 0) sees a huge score
+    cu = torch.tensor([0, T], device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    want = ref.flash_attention_prefill(q, k, v, cu, scale)
+    got = hip.flash_attention_prefill(q, k, v, cu, scale)
+    close(got, want, dtype)
+
+
+def test_decode_matches_prefill_last_row(hip):
+    """Cross-check of the two attention kernels: decode of the last token == last row of prefill."""
+    torch.manual_seed(14)
+    dtype, hq, hkv, d, bs, L = torch.bfloat16, 32, 8, 128, 256, 777
+    k = torch.randn(L, hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(L, hkv, d, device=DEV, dtype=dtype)
+    q = torch.randn(L, hq, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(k, v, [L], bs, hkv, d, dtype)
+    cu = torch.tensor([0, L], device=DEV, dtype=torch.int32)
+    pre = hip.paged_attention_prefill(q, kc, vc, cu, cu, tables, 0.0884)
+    dec = hip.paged_attention_decode(q[-1:].contiguous(), kc, vc, tables,
+                                     torch.tensor([L], device=DEV, dtype=torch.int32), 0.0884)
+    close(dec[0], pre[-1], dtype)
