@@ -49,6 +49,8 @@ def _run(cmd) -> None:
 def build_hip(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")))
+    if not force and _newer(HIP_LIB, srcs + hdrs):
+        return HIP_LIB                       # library is newer than every source: keep it
     os.makedirs(BUILD, exist_ok=True)
     hipcc = _hipcc()
     flags = [f"--offload-arch={ARCH}", "-O3", "-fPIC", "-std=c++17", "-Wall",

@@ -90,6 +90,7 @@ class LLMEngine:
         if self._exited:
             return
         self._exited = True
+        atexit.unregister(self.exit)
         try:
             self.model_runner.call("exit")
         finally:

@@ -194,10 +194,19 @@ class ModelRunner:
         if getattr(self, "_exited", False):
             return
         self._exited = True
-        self.graphs.clear()
-        self.graph_pool = None
         if self.on_gpu:
             torch.cuda.synchronize()
+        # give the device memory back: another engine may be built in this process
+        self.graphs.clear()
+        self._graph_out = {}
+        self.graph_pool = None
+        for layer in self.model.model.layers:
+            layer.self_attn.attn.k_cache = layer.self_attn.attn.v_cache = None
+        self.kv_cache = None
+        self.model = None
+        self._dec_dev = self._pre_dev = None
+        if self.on_gpu:
+            torch.cuda.empty_cache()
         if self.channel is not None:
             try:                    # readers detach before the writer unlinks the segment
                 pg.tp_barrier()
@@ -206,6 +215,26 @@ class ModelRunner:
             self.channel.close()
             self.channel = None
         pg.destroy_tensor_parallel()
+
+    # ================================================================= timing
+    def timer_start(self) -> None:
+        """Every rank: drain the device, meet at a barrier, start a wall clock."""
+        if self.on_gpu:
+            torch.cuda.synchronize()
+        pg.tp_barrier()
+        self._t0 = time.perf_counter()
+
+    def timer_stop(self) -> float:
+        """Every rank: drain, barrier, and return the MAX elapsed seconds over ranks."""
+        if self.on_gpu:
+            torch.cuda.synchronize()
+        pg.tp_barrier()
+        dt = time.perf_counter() - self._t0
+        if self.world_size > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=self.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=pg.tp_group())
+            dt = float(t.item())
+        return dt
 
     # ================================================================ warm-up
     def warmup_model(self) -> None:

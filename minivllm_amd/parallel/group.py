@@ -55,9 +55,13 @@ def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
         kwargs = {}
         if backend == "nccl" and device is not None:
             kwargs["device_id"] = torch.device(device)
+        # under torchrun the launcher already hosts the rendezvous store on MASTER_PORT:
+        # join it (env://) instead of opening a second store on the same port
+        under_launcher = ("TORCHELASTIC_RUN_ID" in os.environ and "MASTER_ADDR" in os.environ
+                          and int(os.environ.get("WORLD_SIZE", "1")) == world_size)
+        init_method = "env://" if under_launcher else f"tcp://{master_addr}:{master_port}"
         dist.init_process_group(
-            backend=backend, init_method=f"tcp://{master_addr}:{master_port}",
-            world_size=world_size, rank=rank,
+            backend=backend, init_method=init_method, world_size=world_size, rank=rank,
             timeout=datetime.timedelta(seconds=timeout_s), **kwargs)
         _OWNS_DEFAULT_GROUP = True
     else:
@@ -74,7 +78,8 @@ def set_tp_for_testing(rank: int, world_size: int) -> None:
 
 def destroy_tensor_parallel() -> None:
     global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP
-    if _TP_GROUP is not None and _OWNS_DEFAULT_GROUP and dist.is_initialized():
+    keep = os.environ.get("MINIVLLM_KEEP_PG") == "1"      # another engine will reuse it
+    if _TP_GROUP is not None and _OWNS_DEFAULT_GROUP and dist.is_initialized() and not keep:
         dist.destroy_process_group()
     _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP = 0, 1, None, False
 

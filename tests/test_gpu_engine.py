@@ -1,0 +1,116 @@
+"""End-to-end engine checks on a real MI355X: HIP path vs the CPU fp32 oracle, hipGraph replay
+vs eager, prefix-cache reuse, preemption."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from minivllm_amd.config import EngineConfig, model_preset
+from minivllm_amd.sampling_parameters import SamplingParams
+
+
+def _cfg(**kw):
+    base = dict(model=model_preset("qwen3-tiny", vocab_size=2048, num_layers=3, head_dim=128,
+                                   hidden_size=256, num_heads=4, num_kv_heads=2,
+                                   intermediate_size=512, max_position=2048),
+                max_num_sequences=8, max_num_batched_tokens=1024, block_size=16,
+                max_model_length=512, eos=-1, max_cached_blocks=256, dtype=torch.bfloat16,
+                device="cuda", enforce_eager=True, seed=3)
+    base.update(kw)
+    return EngineConfig(**base).validate()
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from minivllm_amd.ops import hip  # noqa: F401
+    return True
+
+
+def _prompts(n, lo=5, hi=200, vocab=2048, seed=0):
+    rng = np.random.default_rng(seed)
+    return [rng.integers(0, vocab, size=int(rng.integers(lo, hi))).tolist() for _ in range(n)]
+
+
+def test_gpu_logits_match_cpu_oracle(gpu):
+    """One prefill + one decode step: HIP bf16 logits vs the torch_ref fp32 model carrying the
+    same (bf16-rounded) weights."""
+    from minivllm_amd.engine.model_runner import ModelRunner
+    from minivllm_amd.engine.sequence import Sequence
+    from minivllm_amd.engine.block_manager import BlockManager
+    g = ModelRunner(_cfg(), 0)
+    c = ModelRunner(_cfg(device="cpu", dtype=torch.float32), 0)
+    c.model.load_state_dict({k: v.float().cpu() for k, v in g.model.state_dict().items()})
+    captured = {}
+    for r, name in ((g, "gpu"), (c, "cpu")):
+        orig = r._sample
+
+        def spy(hidden, temps, step, _orig=orig, _name=name, _r=r):
+            captured.setdefault(_name, []).append(
+                _r.model.lm_head.local_logits(hidden).float().cpu())
+            return _orig(hidden, temps, step)
+        r._sample = spy
+    prompts = _prompts(5)
+    for r in (g, c):
+        bm = BlockManager(r.num_kv_blocks, 16)
+        seqs = [Sequence(p, SamplingParams(temperature=0, max_tokens=4), block_size=16) for p in prompts]
+        for s in seqs:
+            bm.allocate(s)
+        toks = r.run(seqs, True)
+        for s, t in zip(seqs, toks):
+            s.append_token(7)             # same continuation on both sides
+            bm.append(s)
+        r.run(seqs, False)
+    for a, b in zip(captured["gpu"], captured["cpu"]):
+        torch.testing.assert_close(a, b, atol=6e-2, rtol=6e-2)
+    g.exit(); c.exit()
+
+
+def test_graph_replay_matches_eager(gpu):
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    prompts = _prompts(6, seed=1)
+    sp = SamplingParams(temperature=0, max_tokens=24, ignore_eos=True)
+    e1 = LLMEngine(_cfg(enforce_eager=True))
+    o1 = e1.generate(prompts, sp)["token_ids"]
+    e1.exit()
+    e2 = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8]))
+    assert e2.model_runner.graphs
+    o2 = e2.generate(prompts, sp)["token_ids"]
+    e2.exit()
+    same = sum(int(a == b) for x, y in zip(o1, o2) for a, b in zip(x, y))
+    total = sum(len(x) for x in o1)
+    assert same / total > 0.9, (same, total)
+
+
+def test_prefix_cache_and_preemption_keep_outputs(gpu):
+    """Shared 64-token prefix (4 full blocks) is reused from the cache; a tiny cache forces
+    recompute preemption; greedy outputs must not change in either case."""
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    rng = np.random.default_rng(5)
+    prefix = rng.integers(0, 2048, size=64).tolist()
+    prompts = [prefix + rng.integers(0, 2048, size=int(n)).tolist() for n in (9, 30, 17, 40)]
+    sp = SamplingParams(temperature=0, max_tokens=40, ignore_eos=True)
+    base = LLMEngine(_cfg())
+    ref = [base.generate([p], sp)["token_ids"][0] for p in prompts]   # one at a time: hits later
+    hits = base.scheduler.block_manager.num_prefix_hits
+    base.exit()
+    assert hits >= 4 * 3
+    small = LLMEngine(_cfg(max_cached_blocks=20))
+    got = small.generate(prompts, sp)["token_ids"]
+    assert small.scheduler.num_preemptions > 0
+    small.exit()
+    same = sum(int(a == b) for x, y in zip(ref, got) for a, b in zip(x, y))
+    total = sum(len(x) for x in ref)
+    assert same / total > 0.9, (same, total)
+
+
+def test_sampling_temperature_runs(gpu):
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    e = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[8]))
+    out = e.generate(_prompts(8, seed=2), SamplingParams(temperature=0.8, max_tokens=16, ignore_eos=True))
+    assert all(len(t) == 16 and all(0 <= x < 2048 for x in t) for t in out["token_ids"])
+    st = e.stats.as_dict()
+    assert st["prefill_tokens"] > 0 and st["decode_steps"] == 15
+    e.exit()
