@@ -1,0 +1,3 @@
+from minivllm_amd.engine.sequence import *  # noqa: F401,F403
+from minivllm_amd.engine import sequence as _m
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})

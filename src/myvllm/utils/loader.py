@@ -1,0 +1,2 @@
+from minivllm_amd.utils import loader as _m
+globals().update({k: v for k, v in vars(_m).items() if not k.startswith("__")})

@@ -1,0 +1,243 @@
+"""Host-only units: Sequence, BlockManager (ref-counting, prefix cache, revive, collision
+guard), Scheduler (prefill priority, budgets, LIFO recompute preemption, finish rules)."""
+import pickle
+
+import pytest
+
+from minivllm_amd.engine.block_manager import BlockManager
+from minivllm_amd.engine.scheduler import Scheduler
+from minivllm_amd.engine.sequence import Sequence, SequenceStatus
+from minivllm_amd.sampling_parameters import SamplingParams
+
+BS = 4
+
+
+def seq(tokens, **kw):
+    return Sequence(list(tokens), SamplingParams(**kw) if kw else None, block_size=BS)
+
+
+# ------------------------------------------------------------------ Sequence
+def test_sequence_properties_and_append():
+    s = seq(range(10), max_tokens=5)
+    assert len(s) == 10 and s.num_blocks == 3 and s.last_block_num_tokens == 2
+    assert s.block(0) == [0, 1, 2, 3] and s.block(2) == [8, 9]
+    s.append_token(99)
+    assert s.last_token == 99 and s.num_tokens == 11 and s.num_completion_tokens == 1
+    assert s.completion_token_ids == [99] and s.prompt_token_ids == list(range(10))
+    s.append_token(100)
+    assert s.num_blocks == 3 and s.last_block_num_tokens == 4
+    with pytest.raises(IndexError):
+        s.block(3)
+
+
+def test_sequence_pickle_is_compact_and_complete():
+    s = seq(range(9), temperature=0.5, max_tokens=7, ignore_eos=True)
+    s.block_table = [3, 1, 2]
+    r = pickle.loads(pickle.dumps(s))
+    assert r.token_ids == list(range(9)) and r.block_table == [3, 1, 2]
+    assert (r.temperature, r.max_tokens, r.ignore_eos, r.block_size) == (0.5, 7, True, BS)
+    s.append_token(42)
+    r = pickle.loads(pickle.dumps(s))                 # after the first completion token only
+    assert r.last_token == 42 and r.num_tokens == 10  # the last token travels
+    assert len(pickle.dumps(s)) < len(pickle.dumps(list(range(2000))))
+
+
+def test_sampling_params_validation():
+    assert SamplingParams(temperature=0).greedy
+    with pytest.raises(ValueError):
+        SamplingParams(temperature=-1)
+    with pytest.raises(ValueError):
+        SamplingParams(max_tokens=0)
+
+
+# -------------------------------------------------------------- BlockManager
+def test_allocate_sets_refcount_and_free_on_deallocate():
+    bm = BlockManager(8, BS)
+    s = seq(range(10))
+    assert bm.can_allocate(s)
+    bm.allocate(s)
+    assert len(s.block_table) == 3 and bm.num_free_blocks == 5
+    assert all(bm.blocks[b].ref_count == 1 for b in s.block_table)
+    bm.deallocate(s)
+    assert bm.num_free_blocks == 8 and s.block_table == [] and s.num_cached_tokens == 0
+    assert all(b.ref_count == 0 for b in bm.blocks)
+
+
+def test_prefix_hit_shares_full_blocks_only():
+    bm = BlockManager(16, BS)
+    a = seq(list(range(8)) + [100, 101])
+    b = seq(list(range(8)) + [200])
+    bm.allocate(a)
+    bm.allocate(b)
+    assert b.num_cached_tokens == 8 and b.block_table[:2] == a.block_table[:2]
+    assert b.block_table[2] != a.block_table[2]                 # partial blocks never shared
+    assert bm.blocks[a.block_table[0]].ref_count == 2
+    bm.deallocate(a)
+    assert bm.blocks[b.block_table[0]].ref_count == 1            # still alive for b
+    assert b.block_table[0] in bm.used_block_ids
+    bm.deallocate(b)
+    assert bm.num_free_blocks == 16
+
+
+def test_hash_chain_needs_matching_prefix():
+    bm = BlockManager(16, BS)
+    a = seq([1, 2, 3, 4, 5, 6, 7, 8, 9])
+    b = seq([9, 9, 9, 9, 5, 6, 7, 8, 9])          # second block equal, first differs
+    bm.allocate(a)
+    bm.allocate(b)
+    assert b.num_cached_tokens == 0
+    assert set(a.block_table).isdisjoint(b.block_table)
+
+
+def test_freed_blocks_are_revived_until_reused():
+    bm = BlockManager(4, BS)
+    a = seq(range(8))
+    bm.allocate(a)
+    blocks = list(a.block_table)
+    bm.deallocate(a)
+    b = seq(list(range(8)) + [77])
+    bm.allocate(b)
+    assert b.block_table[:2] == blocks and b.num_cached_tokens == 8
+    bm.deallocate(b)
+    # burn through the pool with other content: the cached identity must disappear
+    for base in (100, 200):
+        c = seq(range(base, base + 16))
+        bm.allocate(c)
+        bm.deallocate(c)
+    d = seq(list(range(8)) + [1])
+    bm.allocate(d)
+    assert d.num_cached_tokens == 0
+
+
+def test_fully_cached_prompt_still_computes_last_token():
+    bm = BlockManager(8, BS)
+    a = seq(range(8))
+    bm.allocate(a)
+    b = seq(range(8))
+    bm.allocate(b)
+    assert b.block_table == a.block_table and b.num_cached_tokens == 7
+
+
+def test_collision_guard_compares_tokens(monkeypatch):
+    bm = BlockManager(8, BS)
+    monkeypatch.setattr(BlockManager, "compute_hash", staticmethod(lambda t, p=-1: 1234))
+    a, b = seq([1, 2, 3, 4, 5]), seq([9, 9, 9, 9, 5])
+    bm.allocate(a)
+    bm.allocate(b)
+    assert b.num_cached_tokens == 0 and a.block_table[0] != b.block_table[0]
+
+
+def test_append_allocates_at_block_boundary_and_publishes_full_blocks():
+    bm = BlockManager(8, BS)
+    s = seq(range(4))
+    bm.allocate(s)                      # exactly one full block
+    s.append_token(50)                  # token 5 needs a second block
+    assert bm.can_append(s)
+    bm.append(s)
+    assert len(s.block_table) == 2
+    for t in (51, 52):
+        s.append_token(t)
+        bm.append(s)
+        assert len(s.block_table) == 2
+    s.append_token(53)                  # 8 tokens: this step fills block 2
+    bm.append(s)
+    assert bm.blocks[s.block_table[1]].hash != -1
+    other = seq(s.token_ids + [1])
+    bm.allocate(other)
+    assert other.num_cached_tokens == 8
+    # no free block -> cannot start a new one
+    bm2 = BlockManager(1, BS)
+    t = seq(range(4))
+    bm2.allocate(t)
+    t.append_token(1)
+    assert not bm2.can_append(t)
+
+
+def test_compute_hash_is_chained_and_stable():
+    h1 = BlockManager.compute_hash([1, 2, 3, 4])
+    assert h1 == BlockManager.compute_hash([1, 2, 3, 4])
+    assert BlockManager.compute_hash([1, 2, 3, 4], h1) != h1
+    assert BlockManager.compute_hash([1, 2, 3, 5]) != h1
+
+
+# ----------------------------------------------------------------- Scheduler
+def make_sched(blocks=64, max_seqs=4, max_tokens=32, eos=999, max_len=None):
+    return Scheduler(max_seqs, max_tokens, blocks, BS, eos, max_model_length=max_len)
+
+
+def test_prefill_has_priority_and_respects_budgets():
+    sch = make_sched(max_seqs=3, max_tokens=20)
+    seqs = [seq(range(i * 100, i * 100 + 8), max_tokens=4) for i in range(5)]
+    for s in seqs:
+        sch.add_sequence(s)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == seqs[:2]                   # 8 + 8 fits, third would exceed 20
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == seqs[2:3]                  # running is capped at 3 sequences
+    batch, is_prefill = sch.schedule()
+    assert not is_prefill and batch == seqs[:3]               # decode, oldest first
+    assert [s.status for s in seqs[:3]] == [SequenceStatus.RUNNING] * 3
+
+
+def test_finish_on_max_tokens_and_eos():
+    sch = make_sched()
+    a, b = seq(range(5), max_tokens=2), seq(range(5), max_tokens=8)
+    sch.add_sequence(a); sch.add_sequence(b)
+    batch, _ = sch.schedule()
+    assert sch.postprocess(batch, [1, 1]) == []
+    batch, _ = sch.schedule()
+    done = sch.postprocess(batch, [2, 999])                   # a hits max_tokens, b hits eos
+    assert done == [a, b] and sch.is_finished()
+    assert a.completion_token_ids == [1, 2] and b.completion_token_ids == [1, 999]
+    assert sch.block_manager.num_free_blocks == 64
+    c = seq(range(5), max_tokens=3, ignore_eos=True)
+    sch.add_sequence(c)
+    batch, _ = sch.schedule()
+    assert sch.postprocess(batch, [999]) == []                # eos ignored
+
+
+def test_preemption_is_lifo_and_recomputes():
+    sch = make_sched(blocks=4, max_seqs=4, max_tokens=64)
+    a, b = seq(range(7), max_tokens=8), seq(range(100, 107), max_tokens=8)
+    sch.add_sequence(a); sch.add_sequence(b)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == [a, b] and sch.block_manager.num_free_blocks == 0
+    sch.postprocess(batch, [1, 1])                            # both at 8 tokens: blocks full
+    batch, is_prefill = sch.schedule()
+    assert not is_prefill and batch == [a, b]                 # still fits (8 tokens = 2 blocks)
+    sch.postprocess(batch, [2, 2])                            # 9 tokens: each needs a 3rd block
+    batch, is_prefill = sch.schedule()
+    assert not is_prefill and batch == [a]                    # b (newest) was preempted
+    assert b.status == SequenceStatus.WAITING and b.block_table == [] and sch.waiting[0] is b
+    assert sch.num_preemptions == 1
+    sch.postprocess(batch, [3])
+    # b comes back through prefill with its generated tokens once a finishes
+    a.max_tokens = a.num_completion_tokens + 1
+    batch, _ = sch.schedule()
+    if batch == [a]:
+        sch.postprocess(batch, [4])
+        batch, is_prefill = sch.schedule()
+    assert batch == [b] and b.num_tokens == 9
+
+
+def test_decode_candidates_beyond_budget_stay_running():
+    sch = make_sched(max_seqs=2, max_tokens=64)
+    seqs = [seq(range(i * 10, i * 10 + 5), max_tokens=9) for i in range(2)]
+    for s in seqs:
+        sch.add_sequence(s)
+    batch, _ = sch.schedule()
+    sch.postprocess(batch, [1, 1])
+    sch.max_num_sequences = 1                                  # shrink the step budget
+    batch, _ = sch.schedule()
+    assert batch == [seqs[0]] and len(sch.running) == 2        # nothing got lost
+
+
+def test_unschedulable_requests_are_rejected_up_front():
+    sch = make_sched(blocks=4, max_tokens=16, max_len=32)
+    with pytest.raises(ValueError):
+        sch.add_sequence(seq(range(17)))                       # longer than a prefill step
+    with pytest.raises(ValueError):
+        sch.add_sequence(seq(range(8), max_tokens=30))         # exceeds max_model_length
+    big = make_sched(blocks=2, max_tokens=64)
+    with pytest.raises(ValueError):
+        big.add_sequence(seq(range(8), max_tokens=8))          # needs 4 blocks, cache has 2

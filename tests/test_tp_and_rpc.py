@@ -1,0 +1,144 @@
+"""Tensor parallelism without a cluster: shard math for tp in {1,2,4,8} with no backend,
+the shared-memory control channel across processes, and the full engine at world_size 2
+over gloo on CPU (TP=2 tokens == TP=1 tokens)."""
+import multiprocessing as mp
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from minivllm_amd.config import EngineConfig, ModelConfig
+from minivllm_amd.engine.rpc import ShmBroadcastChannel, decode_message, encode_message
+from minivllm_amd.parallel import group as pg
+from minivllm_amd.sampling_parameters import SamplingParams
+
+
+# ------------------------------------------------------------ shard math
+@pytest.mark.parametrize("tp", [1, 2, 4, 8])
+def test_linear_shards_reassemble(tp):
+    from minivllm_amd.layers.linear import (ColumnParallelLinear, MergedColumnParallelLinear,
+                                            QKVColumnParallelLinear, RowParallelLinear)
+    torch.manual_seed(0)
+    hid, inter, H, HKV, D = 64, 96 * 2, 16, 8, 8
+    x = torch.randn(5, hid)
+    w_col, w_gate, w_up = torch.randn(inter, hid), torch.randn(inter, hid), torch.randn(inter, hid)
+    wq, wk, wv = torch.randn(H * D, hid), torch.randn(HKV * D, hid), torch.randn(HKV * D, hid)
+    w_row = torch.randn(hid, inter)
+    col_out, gate_out, up_out, q_out, k_out, v_out, row_out = [], [], [], [], [], [], 0
+    for r in range(tp):
+        kw = dict(tp_rank=r, tp_size=tp)
+        c = ColumnParallelLinear(hid, inter, **kw); c.weight.weight_loader(c.weight, w_col)
+        col_out.append(c(x))
+        m = MergedColumnParallelLinear(hid, [inter, inter], **kw)
+        m.weight.weight_loader(m.weight, w_gate, 0); m.weight.weight_loader(m.weight, w_up, 1)
+        g, u = m(x).chunk(2, -1)
+        gate_out.append(g); up_out.append(u)
+        qkv = QKVColumnParallelLinear(hid, D, H, HKV, **kw)
+        for t, sid in ((wq, "q"), (wk, "k"), (wv, "v")):
+            qkv.weight.weight_loader(qkv.weight, t, sid)
+        q, k, v = qkv(x).split([H * D // tp, HKV * D // tp, HKV * D // tp], -1)
+        q_out.append(q); k_out.append(k); v_out.append(v)
+        row = RowParallelLinear(inter, hid, reduce_results=False, **kw)
+        row.weight.weight_loader(row.weight, w_row)
+        xs = torch.randn(5, inter, generator=torch.Generator().manual_seed(1))
+        row_out = row_out + row(xs[:, r * inter // tp:(r + 1) * inter // tp])
+    xs = torch.randn(5, inter, generator=torch.Generator().manual_seed(1))
+    tol = dict(atol=1e-4, rtol=1e-4)
+    torch.testing.assert_close(torch.cat(col_out, -1), x @ w_col.T, **tol)
+    torch.testing.assert_close(torch.cat(gate_out, -1), x @ w_gate.T, **tol)
+    torch.testing.assert_close(torch.cat(up_out, -1), x @ w_up.T, **tol)
+    torch.testing.assert_close(torch.cat(q_out, -1), x @ wq.T, **tol)
+    torch.testing.assert_close(torch.cat(k_out, -1), x @ wk.T, **tol)
+    torch.testing.assert_close(torch.cat(v_out, -1), x @ wv.T, **tol)
+    torch.testing.assert_close(row_out, xs @ w_row.T, **tol)
+
+
+@pytest.mark.parametrize("tp", [2, 8])
+def test_vocab_parallel_embedding_pads_odd_vocab(tp):
+    from minivllm_amd.layers.embedding_head import VocabParallelEmbedding
+    V, hid = 151643 // 1000, 16            # odd vocabulary like the reference demo's
+    full = torch.randn(V, hid)
+    ids = torch.tensor([0, 1, V - 1, V // 2])
+    total = 0
+    for r in range(tp):
+        e = VocabParallelEmbedding(V, hid, tp_rank=r, tp_size=tp)
+        assert e.num_embeddings_padded % tp == 0 and e.num_embeddings_padded >= V
+        e.weight.weight_loader(e.weight, full)
+        mask = (ids >= e.vocab_start) & (ids < e.vocab_end)
+        local = (ids - e.vocab_start) * mask
+        total = total + torch.nn.functional.embedding(local, e.weight) * mask[:, None]
+    torch.testing.assert_close(total, full[ids])
+
+
+# -------------------------------------------------------- control channel
+def test_message_codec_roundtrip():
+    arrays = {"a": np.arange(7, dtype=np.int32), "b": np.ones((2, 3), np.float32),
+              "empty": np.zeros((0,), np.int32)}
+    m, s, a = decode_message(encode_message("run_batch", {"x": 1, "flag": True}, arrays))
+    assert m == "run_batch" and s == {"x": 1, "flag": True}
+    for k in arrays:
+        assert a[k].dtype == arrays[k].dtype and np.array_equal(a[k], arrays[k])
+
+
+def _reader(name, idx, n_msgs, q):
+    ch = ShmBroadcastChannel(name, 2, create=False)
+    got = []
+    for _ in range(n_msgs):
+        m, s, a = ch.recv(idx, timeout_s=30)
+        got.append((m, s["i"], int(a["v"].sum())))
+    ch.close()
+    q.put((idx, got))
+
+
+def test_shm_channel_broadcasts_in_order_without_overwrite():
+    name = f"mvl_test_{os.getpid()}"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    writer = ShmBroadcastChannel(name, 2, create=True, size=1 << 16)
+    procs = [ctx.Process(target=_reader, args=(name, i, 50, q)) for i in range(2)]
+    for p in procs:
+        p.start()
+    for i in range(50):                   # back-to-back sends: acks must gate the reuse
+        writer.send("step", {"i": i}, {"v": np.full(100, i, np.int64)})
+    res = dict(q.get(timeout=60) for _ in procs)
+    for p in procs:
+        p.join(timeout=30)
+    writer.close()
+    want = [("step", i, 100 * i) for i in range(50)]
+    assert res[0] == want and res[1] == want
+    with pytest.raises(ValueError):
+        big = ShmBroadcastChannel(name + "b", 1, create=True, size=1024)
+        try:
+            big.send("x", {}, {"v": np.zeros(4096, np.int64)})
+        finally:
+            big.close()
+
+
+# ------------------------------------------------------- engine, TP=2 on CPU
+def _cfg(world, port):
+    model = ModelConfig(vocab_size=331, hidden_size=64, num_heads=4, num_kv_heads=2, head_dim=32,
+                        intermediate_size=96, num_layers=2, max_position=256, base=10000.0,
+                        tie_word_embeddings=True)
+    return EngineConfig(model=model, max_num_sequences=4, max_num_batched_tokens=64, block_size=8,
+                        max_model_length=96, eos=-1, device="cpu", dtype=torch.float32, seed=11,
+                        world_size=world, master_port=port, max_cached_blocks=24)
+
+
+def _generate(world, port):
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    eng = LLMEngine(_cfg(world, port))
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(0, 331, size=n).tolist() for n in (5, 21, 9, 16, 30)]
+    out = eng.generate(prompts, SamplingParams(temperature=0, max_tokens=10, ignore_eos=True))
+    stats = (eng.scheduler.num_preemptions, eng.stats.decode_steps)
+    eng.exit()
+    return out["token_ids"], stats
+
+
+def test_tp2_gloo_matches_tp1():
+    port = 29600 + os.getpid() % 300
+    single, _ = _generate(1, port)
+    double, stats = _generate(2, port + 1)          # spawns one gloo worker process
+    assert double == single
+    assert not pg.is_initialized()                  # exit() tore the group down
