@@ -53,7 +53,8 @@ def main():
         cfg["checkpoint_path"] = a.checkpoint
         cfg["model_name_or_path"] = a.checkpoint
     if a.tiny:
-        cfg.update(model_preset="qwen3-tiny", max_model_length=512, max_num_batched_tokens=1024,
+        cfg.update(model_preset="qwen3-tiny", max_position=2048, max_model_length=1024,
+                   max_num_batched_tokens=2048,
                    max_num_sequences=16, block_size=16, eos=257, dtype="fp32")
         a.max_tokens = min(a.max_tokens, 16)
     llm = LLM(config=cfg)

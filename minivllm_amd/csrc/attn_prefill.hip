@@ -22,6 +22,7 @@
 //  * the 1-D grid is remapped so that workgroups sharing an XCD (and its L2) walk the query
 //    heads of one KV head and adjacent Q tiles of one sequence, heaviest Q tiles first.
 #include "common.h"
+#include <type_traits>
 
 using namespace mvl;
 
@@ -32,6 +33,7 @@ namespace {
 constexpr int kBM = 128;           // query rows per workgroup
 constexpr int kBN = 64;            // kv rows per tile
 constexpr int kThreads = 256;
+constexpr float kRescaleThr = 6.0f;   // log2 units: P <= 64 between rescales
 
 struct PrefillArgs {
     const uint16_t* q; long q_stride_t; long q_stride_h;
@@ -56,9 +58,8 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     constexpr int ITER = kBN * CPR / kThreads; // staging chunks per thread per tile
     constexpr int TILE_BYTES = kBN * D * 2;
 
+    // two buffers of {K tile, V tile}; tile t lives in buffer t & 1
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* k_lds = smem;
-    char* v_lds = smem + TILE_BYTES;
 
     // ---- work decomposition: XCD-aware remap of the linear block id -----------------
     int id = blockIdx.x;
@@ -105,13 +106,18 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     const int last_pos = min(q0 + kBM - 1, q_len - 1) + pos_off;
     const int n_tiles = last_pos / kBN + 1;
 
-    // ---- staging coordinates -----------------------------------------------------------
+    // ---- staging: global -> LDS by LDS-DMA (no staging registers, no ds_write) ----------
+    // One wave-instruction moves 64 x 16 B to 1 KiB of consecutive LDS (lane l lands at
+    // base + 16 l), so the XOR swizzle of the LDS image is applied to the SOURCE address:
+    // the slot (row, pos) of the image receives global chunk pos ^ x(row), which is exactly
+    // where tile_off(row, ch) looks for chunk ch.
     int st_row[ITER], st_ch[ITER];
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-        const int c = i * kThreads + threadIdx.x;
+        const int c = i * kThreads + threadIdx.x;       // linear 16-byte slot of the tile image
         st_row[i] = c / CPR;
-        st_ch[i] = c % CPR;
+        const int pos = c % CPR;
+        st_ch[i] = pos ^ ((((st_row[i] & 3) << 2) | ((st_row[i] >> 2) & 3)) & (CPR - 1));
     }
     const int bs_mask = (1 << a.bs_log2) - 1;
     const int* bt = PAGED ? a.block_tables + (long)b * a.bt_stride : nullptr;
@@ -126,7 +132,8 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
             }
         }
     };
-    auto issue_loads = [&](int t, const int (&ids)[ITER], u32x4_t (&kr)[ITER], u32x4_t (&vr)[ITER]) {
+    auto stage_tile = [&](int t, const int (&ids)[ITER]) {
+        char* kb = smem + (t & 1) * (2 * TILE_BYTES);
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
             const int tok = min(t * kBN + st_row[i], k_len - 1);
@@ -135,16 +142,9 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
                 off = (long)ids[i] * a.cs_b + (long)(tok & bs_mask) * a.k_stride_t + head_off + st_ch[i] * 8;
             else
                 off = (long)(k_start + tok) * a.k_stride_t + head_off + st_ch[i] * 8;
-            kr[i] = *reinterpret_cast<const u32x4_t*>(a.k + off);
-            vr[i] = *reinterpret_cast<const u32x4_t*>(a.v + off);
-        }
-    };
-    auto write_lds = [&](const u32x4_t (&kr)[ITER], const u32x4_t (&vr)[ITER]) {
-#pragma unroll
-        for (int i = 0; i < ITER; ++i) {
-            const int o = tile_off<CPR>(st_row[i], st_ch[i]);
-            *reinterpret_cast<u32x4_t*>(k_lds + o) = kr[i];
-            *reinterpret_cast<u32x4_t*>(v_lds + o) = vr[i];
+            char* dst = kb + (i * kThreads + w * 64) * 16;          // wave-uniform
+            glds16(a.k + off, dst);
+            glds16(a.v + off, dst + TILE_BYTES);
         }
     };
 
@@ -155,16 +155,14 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[n][e] = 0.f;
 
-    u32x4_t kreg[ITER], vreg[ITER];
     int ids_next[ITER];
     {
         int ids[ITER];
         load_block_ids(0, ids);
-        issue_loads(0, ids, kreg, vreg);
+        stage_tile(0, ids);
         if (n_tiles > 1) load_block_ids(1, ids_next);
     }
-    write_lds(kreg, vreg);
-    __syncthreads();
+    __syncthreads();                         // drains the LDS-DMA (vmcnt) and meets the waves
 
     // transposed-read lane constants: 16-lane group gq = lane >> 4; (gq & 1) picks the
     // 16-column half of a 32-wide d block, hh = gq >> 1 picks the key rows
@@ -173,88 +171,103 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     const int tr_chunk0 = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
     const int tr_sub = (i16 & 1) * 8;
 
-    for (int t = 0; t < n_tiles; ++t) {
-        if (t + 1 < n_tiles) {
-            issue_loads(t + 1, ids_next, kreg, vreg);
-            if (t + 2 < n_tiles) load_block_ids(t + 2, ids_next);
-        }
-        const int kv0 = t * kBN;
-        if (wave_live && kv0 <= wave_max_pos) {
-            // ---- S^T[kv][q] = K . Q^T : two 32-row sub-tiles --------------------------
-            f32x16_t s_acc[2];
+    // One KV tile for this wave: S^T = K.Q^T, online softmax, O^T += V^T.P^T.
+    // m_run is the reference point of the exponentials, not necessarily the true row
+    // maximum: it is only moved (and O, l rescaled) when some row's maximum outgrows it by
+    // more than kRescaleThr (log2 units), so most tiles skip the O-wide rescale; P stays
+    // <= 2^kRescaleThr, far inside bf16/fp16 range.
+    auto process_tile = [&](auto mask_tag, int kv0, const char* k_lds, const char* v_lds) {
+        constexpr bool MASK = decltype(mask_tag)::value;
+        f32x16_t s_acc[2];
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub) {
+        for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) s_acc[sub][e] = 0.f;
+            for (int e = 0; e < 16; ++e) s_acc[sub][e] = 0.f;
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    const u32x4_t kv = *reinterpret_cast<const u32x4_t*>(
-                        k_lds + tile_off<CPR>(32 * sub + r32, 2 * s + hh));
-                    s_acc[sub] = DT::mfma32(__builtin_bit_cast(vec8, kv), qfrag[s], s_acc[sub]);
-                }
+            for (int s = 0; s < KSTEPS; ++s) {
+                const u32x4_t kv = *reinterpret_cast<const u32x4_t*>(
+                    k_lds + tile_off<CPR>(32 * sub + r32, 2 * s + hh));
+                s_acc[sub] = DT::mfma32(__builtin_bit_cast(vec8, kv), qfrag[s], s_acc[sub]);
             }
-            // lane (r32, hh) holds, for query row r32, keys kv0 + 32 sub + (e&3) + 8 (e>>2) + 4 hh
-            const bool need_mask = kv0 + kBN - 1 > wave_min_pos;
-            float m_tile = -INFINITY;
+        }
+        // lane (r32, hh) holds, for query row r32, keys kv0 + 32 sub + (e&3) + 8 (e>>2) + 4 hh
+        float m_tile = -INFINITY;
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+        for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    float v = s_acc[sub][e] * a.scale_log2;
-                    if (need_mask) {
-                        const int kv = kv0 + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * hh;
-                        if (kv > my_pos) v = -INFINITY;
-                    }
-                    s_acc[sub][e] = v;
-                    m_tile = fmaxf(m_tile, v);
+            for (int e = 0; e < 16; ++e) {
+                if (MASK) {
+                    const int kv = kv0 + 32 * sub + (e & 3) + 8 * (e >> 2) + 4 * hh;
+                    if (kv > my_pos) s_acc[sub][e] = -INFINITY;
                 }
-            m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64));
+                m_tile = fmaxf(m_tile, s_acc[sub][e]);
+            }
+        m_tile = fmaxf(m_tile, __shfl_xor(m_tile, 32, 64)) * a.scale_log2;   // scale > 0
+        // rescale only when needed (wave-uniform decision; NaN-safe: -inf - -inf counts)
+        if (!__all(m_tile - m_run <= kRescaleThr)) {
             const float m_new = fmaxf(m_run, m_tile);
-            // a row past q_len (clamped duplicate) or a fully masked row keeps m = -inf:
-            // use a finite stand-in so that exp2 sees (-inf) - finite = -inf -> 0
-            const float m_use = (m_new == -INFINITY) ? 0.f : m_new;
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_use);
-            float psum = 0.f;
-            vec8 pfrag[2][2];
+            // a row with nothing visible yet keeps m = -inf; exp2 then sees -inf -> 0
+            const float alpha = (m_new == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f(m_run - m_new);
+            l_run *= alpha;
+#pragma unroll
+            for (int n = 0; n < NDB; ++n) acc_o[n] *= alpha;
+            m_run = m_new;
+        }
+        const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
+        float psum = 0.f;
+        vec8 pfrag[2][2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                float p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    p[j] = __builtin_amdgcn_exp2f(fmaf(s_acc[sub][8 * s + j], a.scale_log2, -m_use));
+                    psum += p[j];
+                }
+                pfrag[sub][s] = __builtin_bit_cast(vec8, pack8<CODE>(p));
+            }
+        l_run += psum;
+#pragma unroll
+        for (int n = 0; n < NDB; ++n) {
 #pragma unroll
             for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
                 for (int s = 0; s < 2; ++s) {
-                    float p[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        p[j] = __builtin_amdgcn_exp2f(s_acc[sub][8 * s + j] - m_use);
-                        psum += p[j];
-                    }
-                    pfrag[sub][s] = __builtin_bit_cast(vec8, pack8<CODE>(p));
+                    // k-slot j of lane half hh <-> key 32 sub + 16 s + 8 (j>>2) + 4 hh + (j&3)
+                    const int row = 32 * sub + 16 * s + tr_row0;
+                    const int ch = 4 * n + tr_chunk0;
+                    const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(row, ch) + tr_sub);
+                    const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(row + 8, ch) + tr_sub);
+                    const s16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    acc_o[n] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[sub][s], acc_o[n]);
                 }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
+        }
+    };
 
-            // ---- O^T[d][q] += V^T . P^T ---------------------------------------------
-#pragma unroll
-            for (int n = 0; n < NDB; ++n) {
-                acc_o[n] *= alpha;
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        // k-slot j of lane half hh <-> key 32 sub + 16 s + 8 (j>>2) + 4 hh + (j&3)
-                        const int row = 32 * sub + 16 * s + tr_row0;
-                        const int ch = 4 * n + tr_chunk0;
-                        const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(row, ch) + tr_sub);
-                        const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(row + 8, ch) + tr_sub);
-                        const s16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc_o[n] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[sub][s], acc_o[n]);
-                    }
+    // Two loops instead of a per-tile branch (one copy of the tile body per loop keeps the
+    // register allocation at the single-variant level): tiles wholly below the workgroup's
+    // first query row need no mask; the last few (diagonal) tiles apply it.
+    auto run_tiles = [&](auto mask_tag, int t_begin, int t_end) {
+        for (int t = t_begin; t < t_end; ++t) {
+            if (t + 1 < n_tiles) {
+                // buffer (t+1)&1 was last read in iteration t-1; the barrier that closed it
+                // ordered those reads before this DMA
+                stage_tile(t + 1, ids_next);
+                if (t + 2 < n_tiles) load_block_ids(t + 2, ids_next);
             }
+            const int kv0 = t * kBN;
+            if (wave_live && kv0 <= wave_max_pos) {
+                const char* k_lds = smem + (t & 1) * (2 * TILE_BYTES);
+                process_tile(mask_tag, kv0, k_lds, k_lds + TILE_BYTES);
+            }
+            if (t + 1 < n_tiles) __syncthreads();    // tile t+1 has landed, tile t is free
         }
-        if (t + 1 < n_tiles) {
-            __syncthreads();                 // every wave is done reading tile t
-            write_lds(kreg, vreg);
-            __syncthreads();
-        }
-    }
+    };
+    const int t_split = min(n_tiles, (q0 + pos_off + 1) / kBN);   // uniform for the workgroup
+    run_tiles(std::false_type{}, 0, t_split);
+    run_tiles(std::true_type{}, t_split, n_tiles);
 
     // ---- epilogue: O[q][d] = O^T / l --------------------------------------------------
     l_run += __shfl_xor(l_run, 32, 64);
@@ -276,7 +289,7 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 
 template <int CODE, int D, bool PAGED>
 int launch_prefill(PrefillArgs a, hipStream_t st) {
-    const size_t lds = 2 * (size_t)kBN * D * 2;
+    const size_t lds = 2 * 2 * (size_t)kBN * D * 2;      // double-buffered K and V tiles
     flash_prefill_kernel<CODE, D, PAGED><<<a.total_wg, kThreads, lds, st>>>(a);
     return MVL_CHECK_LAUNCH();
 }

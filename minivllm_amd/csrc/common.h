@@ -54,9 +54,19 @@ template <> struct DType<1> {
     }
 };
 
+// two floats -> one packed 32-bit word (element 0 in the low half): a single
+// v_cvt_pk_bf16_f32 / v_cvt_pkrtz-free f16 pack instead of two converts and an OR
 template <int CODE>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)DType<CODE>::from_float(lo) | ((uint32_t)DType<CODE>::from_float(hi) << 16);
+    typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+    const f32x2_t f = {lo, hi};
+    if (CODE == 0) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+    } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+        return __builtin_bit_cast(uint32_t, __builtin_convertvector(f, f16x2_t));
+    }
 }
 
 template <int CODE>
@@ -121,6 +131,15 @@ __device__ __forceinline__ s16x4_t lds_read_tr16(const char* lds_base, int byte_
     typedef __attribute__((address_space(3))) s16x4_t* lds_ptr_t;
     return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
         (lds_ptr_t)(__attribute__((address_space(3))) char*)(lds_base + byte_off));
+}
+
+// Asynchronous 16-byte-per-lane global -> LDS copy (LDS-DMA).  `lds_wave_base` must be the same
+// for every lane of the wave: lane l's 16 bytes land at lds_wave_base + 16 l.  The source
+// address is per lane.
+__device__ __forceinline__ void glds16(const void* gptr, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds(
+        (const __attribute__((address_space(1))) void*)gptr,
+        (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 constexpr float kLog2e = 1.4426950408889634f;

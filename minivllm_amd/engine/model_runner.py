@@ -123,7 +123,7 @@ class ModelRunner:
             self.warmup_model()
             self.allocate_kv_cache()
             if self.on_gpu and not self.enforce_eager:
-                self.capture_graphs()
+                self._capture_graphs_or_fall_back()
 
         # ---- control channel --------------------------------------------
         self.channel: Optional[ShmBroadcastChannel] = None
@@ -505,6 +505,26 @@ class ModelRunner:
         return self.sampler(logits, temperatures)
 
     # ================================================================ graphs
+    def _capture_graphs_or_fall_back(self) -> None:
+        """Graph capture must succeed on every rank or on none: a rank replaying a graph
+        while another runs eagerly would issue different collective sequences."""
+        ok = 1
+        try:
+            self.capture_graphs()
+        except Exception as e:            # e.g. a collective backend that cannot be captured
+            ok = 0
+            print(f"[rank {self.rank}] hipGraph capture failed ({type(e).__name__}: {e}); "
+                  f"decoding eagerly", flush=True)
+        if self.world_size > 1:
+            t = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=pg.tp_group())
+            ok = int(t.item())
+        if not ok:
+            self.graphs.clear()
+            self._graph_out = {}
+            self.graph_pool = None
+            self.enforce_eager = True
+
     @torch.inference_mode()
     def capture_graphs(self) -> None:
         """Capture one hipGraph per decode batch-size bucket, largest first so that all

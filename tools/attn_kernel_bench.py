@@ -1,0 +1,73 @@
+#!/usr/bin/env python3
+"""Runs ONLY the two attention kernels on serving-sized shapes (for rocprofv3 passes and
+quick timing): prefill B x S causal (paged, block 256) and decode B x ctx (paged, block 256),
+Qwen3-8B heads (32/8/128), bf16.
+
+    python tools/attn_kernel_bench.py [--mode prefill|decode|both] [--iters N]
+"""
+import argparse
+import math
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from minivllm_amd.ops import hip
+
+
+def cache(nb, bs, hkv, d):
+    return torch.randn(nb, hkv, bs, d, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="both")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--hq", type=int, default=32)
+    ap.add_argument("--hkv", type=int, default=8)
+    ap.add_argument("--prefill", default="16x1024,4x4096,1x16384,1x32768")
+    ap.add_argument("--decode", default="256x1024,64x4096,8x16384,1x32768")
+    a = ap.parse_args()
+    hq, hkv, d, bs = a.hq, a.hkv, 128, 256
+    scale = 1 / math.sqrt(d)
+    if a.mode in ("prefill", "both"):
+        for spec in a.prefill.split(","):
+            B, S = map(int, spec.split("x"))
+            nblk = (S + bs - 1) // bs
+            kc, vc = cache(B * nblk, bs, hkv, d), cache(B * nblk, bs, hkv, d)
+            q = torch.randn(B * S, hq, d, device="cuda", dtype=torch.bfloat16)
+            cu = torch.arange(0, (B + 1) * S, S, device="cuda", dtype=torch.int32)
+            bt = torch.arange(B * nblk, device="cuda", dtype=torch.int32).view(B, nblk)
+            t = timeit(lambda: hip.paged_attention_prefill(q, kc, vc, cu, cu, bt, scale, S), a.iters)
+            fl = 4 * hq * d * B * S * (S + 1) / 2
+            print(f"prefill B={B} S={S}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TFLOP/s (causal)", flush=True)
+            del kc, vc, q
+    if a.mode in ("decode", "both"):
+        for spec in a.decode.split(","):
+            B, S = map(int, spec.split("x"))
+            nblk = (S + bs - 1) // bs
+            kc, vc = cache(B * nblk, bs, hkv, d), cache(B * nblk, bs, hkv, d)
+            q = torch.randn(B, hq, d, device="cuda", dtype=torch.bfloat16)
+            ctx = torch.full((B,), S, device="cuda", dtype=torch.int32)
+            bt = torch.arange(B * nblk, device="cuda", dtype=torch.int32).view(B, nblk)
+            t = timeit(lambda: hip.paged_attention_decode(q, kc, vc, bt, ctx, scale, S), a.iters)
+            by = 2 * B * S * hkv * d * 2
+            print(f"decode  B={B} ctx={S}: {t*1e3:8.3f} ms  {by/t/1e12:6.2f} TB/s KV stream", flush=True)
+            del kc, vc, q
+
+
+if __name__ == "__main__":
+    main()
