@@ -37,6 +37,7 @@ from minivllm_amd.layers.sampler import SamplerLayer
 from minivllm_amd.models.qwen3 import Qwen3ForCausalLM
 from minivllm_amd.parallel import group as pg
 from minivllm_amd.utils.context import reset_context, set_context
+from minivllm_amd.utils.profiling import trace_range
 
 
 @dataclass
@@ -370,7 +371,7 @@ class ModelRunner:
         batch.step = self.step_counter
         if self.world_size > 1 and self.rank == 0:
             self.channel.send("run_batch", batch.scalars(), batch.arrays)
-        with torch.inference_mode():
+        with torch.inference_mode(), trace_range("prefill_step" if is_prefill else "decode_step"):
             return self.execute(batch)
 
     # ------------------------------------------------------------- uploads

@@ -142,7 +142,8 @@ class RowParallelLinear(LinearBase):
         param.data.copy_(loaded_weight.narrow(1, self.tp_rank * shard, shard))
 
     def forward(self, x):
-        y = F.linear(x, self.weight, self.bias if self.tp_rank == 0 else None)
+        bias = self.bias if self.tp_rank == 0 else None
         if self.tp_size > 1 and self.reduce_results:
-            y = pg.tp_all_reduce(y)
-        return y
+            from minivllm_amd.parallel.overlap import row_parallel_linear
+            return row_parallel_linear(x, self.weight, bias)
+        return F.linear(x, self.weight, bias)

@@ -1,0 +1,60 @@
+"""Row-parallel GEMM with its all-reduce pipelined over token chunks.
+
+The reference all-reduces the whole ``[T, hidden]`` output on the compute stream after the GEMM
+has finished (reference: src/myvllm/layers/linear.py:216-221), so the interconnect idles during
+the GEMM and the matrix cores idle during the collective.  For prefill-sized inputs this splits
+the tokens into chunks: chunk i is all-reduced (RCCL runs collectives on its own HIP stream,
+ordered after the producing GEMM by an event) while the GEMM of chunk i+1 runs on the compute
+stream.  xGMI is point-to-point and ring collectives are per-link bound, so chunks are kept
+large (>= ``min_chunk_tokens`` rows, a few MiB each) — small chunks would turn a
+bandwidth-bound collective into several latency-bound ones.
+
+Decode-sized inputs (a few hundred rows) take the plain path: one GEMM, one all-reduce.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+from . import group as pg
+
+# below this many rows per chunk the collective is latency-bound and splitting only hurts
+MIN_CHUNK_TOKENS = 2048
+MAX_CHUNKS = 4
+
+
+def plan_chunks(num_tokens: int, min_chunk_tokens: int = MIN_CHUNK_TOKENS,
+                max_chunks: int = MAX_CHUNKS) -> int:
+    if num_tokens < 2 * min_chunk_tokens:
+        return 1
+    return max(1, min(max_chunks, num_tokens // min_chunk_tokens))
+
+
+def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                        num_chunks: Optional[int] = None) -> torch.Tensor:
+    """``all_reduce(x @ weight.T (+ bias))`` over the TP group, chunk-pipelined when it pays.
+    ``bias`` must already be None on every rank but one."""
+    group = pg.tp_group()
+    if group is None:
+        return F.linear(x, weight, bias)
+    T = x.shape[0] if x.dim() == 2 else 0
+    n = plan_chunks(T) if num_chunks is None else num_chunks
+    if n <= 1 or x.dim() != 2:
+        y = F.linear(x, weight, bias)
+        dist.all_reduce(y, group=group)
+        return y
+    out = torch.empty((T, weight.shape[0]), dtype=x.dtype, device=x.device)
+    works = []
+    bounds = [T * i // n for i in range(n + 1)]
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        y = out[lo:hi]
+        torch.matmul(x[lo:hi], weight.t(), out=y)
+        if bias is not None:
+            y.add_(bias)
+        works.append(dist.all_reduce(y, group=group, async_op=True))
+    for w in works:
+        w.wait()              # makes the compute stream wait for the collective's event
+    return out

@@ -142,3 +142,37 @@ def test_tp2_gloo_matches_tp1():
     double, stats = _generate(2, port + 1)          # spawns one gloo worker process
     assert double == single
     assert not pg.is_initialized()                  # exit() tore the group down
+
+
+# ------------------------------------------- chunk-pipelined row-parallel GEMM
+def _overlap_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from minivllm_amd.parallel import group as g
+    from minivllm_amd.parallel.overlap import plan_chunks, row_parallel_linear
+    g.init_tensor_parallel(rank, world, "gloo", "127.0.0.1", port)
+    gen = torch.Generator().manual_seed(0)
+    x_full = torch.randn(300, 64, generator=gen)
+    w_full = torch.randn(48, 64, generator=gen)
+    bias = torch.randn(48, generator=gen)
+    xs, ws = x_full[:, rank * 32:(rank + 1) * 32], w_full[:, rank * 32:(rank + 1) * 32]
+    res = {}
+    for n in (1, 3, 4):
+        res[n] = row_parallel_linear(xs.contiguous(), ws.contiguous(), bias if rank == 0 else None, n)
+    want = x_full @ w_full.T + bias
+    ok = all(torch.allclose(v, want, atol=1e-4, rtol=1e-4) for v in res.values())
+    q.put((rank, ok, plan_chunks(100), plan_chunks(16384), plan_chunks(5000)))
+    g.destroy_tensor_parallel()
+
+
+def test_chunked_row_parallel_linear_matches_dense():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29900 + os.getpid() % 90
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+    assert all(o[1] for o in out)
+    assert out[0][2:] == (1, 4, 2)
