@@ -19,7 +19,9 @@ Each timed region is bracketed by device synchronise + barrier on every rank and
 time is the MAX over ranks.  Rank 0 prints ONE JSON line; ``value`` is the whole-job decode
 tok/s of the flagship model, the prefill number and the second model are extra keys.
 With N > 1 the model is tensor-parallel over the N GPUs (RCCL over xGMI) and the global batch
-is the same as with 1 GPU (strong scaling).
+is the same as with 1 GPU (strong scaling); that is the headline ``value``.  The same N GPUs are
+then also measured as N independent single-GPU replicas (data parallel, weak scaling) and
+reported under ``data_parallel_replicas``.
 """
 from __future__ import annotations
 
@@ -51,20 +53,41 @@ def make_config(args, model_name: str, world: int) -> EngineConfig:
         max_model_length=max(args.seq_len + args.steps + args.warmup + 64, 2048),
         gpu_memory_utilization=0.85, dtype=torch.bfloat16, device="cuda", seed=0,
         master_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), master_port=port,
+        # MINIVLLM_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal only)
+        dist_backend=os.environ.get("MINIVLLM_DIST_BACKEND", "auto"),
         max_cached_blocks=args.kv_blocks).validate()
 
 
-def bench_model(args, model_name: str, rank: int, world: int):
+class _ReplicaTimer:
+    """Timing bracket for data-parallel replicas: every rank drains its device, meets the
+    others at a barrier of the job-wide process group, and the elapsed time is the MAX."""
+
+    def call(self, what: str):
+        import torch.distributed as dist
+        torch.cuda.synchronize()
+        dist.barrier()
+        if what == "timer_start":
+            self.t0 = time.perf_counter()
+            return None
+        t = torch.tensor([time.perf_counter() - self.t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+
+def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = False):
+    """``replicas=False``: one tensor-parallel engine over all ranks (rank 0 drives).
+    ``replicas=True``: every rank runs its own single-GPU engine on the same workload
+    (data parallel); the returned numbers are per replica."""
     from minivllm_amd.engine.llm_engine import LLMEngine, run_worker
     from minivllm_amd.sampling_parameters import SamplingParams
-    cfg = make_config(args, model_name, world)
-    if rank != 0:
+    cfg = make_config(args, model_name, 1 if replicas else world)
+    if rank != 0 and not replicas:
         run_worker(cfg, rank)                    # serves rank 0 until 'exit'
         return None
     t_init = time.perf_counter()
     eng = LLMEngine(cfg, spawn_workers=False)
     init_s = time.perf_counter() - t_init
-    runner = eng.model_runner
+    runner = _ReplicaTimer() if replicas else eng.model_runner
     rng = np.random.default_rng(0)
     vocab = cfg.model.vocab_size
     W, K, S, B = args.warmup, args.steps, args.seq_len, args.batch
@@ -72,7 +95,7 @@ def bench_model(args, model_name: str, rank: int, world: int):
     def prompts(n, length):
         return rng.integers(0, vocab, size=(n, length)).tolist()
 
-    res = {"init_s": round(init_s, 1), "kv_blocks": runner.num_kv_blocks}
+    res = {"init_s": round(init_s, 1), "kv_blocks": eng.model_runner.num_kv_blocks}
 
     # ------------------------------------------------------------ prefill phase
     if args.mode in ("both", "prefill"):
@@ -136,21 +159,30 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug)")
     ap.add_argument("--kv-blocks", type=int, default=None)
     ap.add_argument("--port", type=int, default=29533)
+    ap.add_argument("--no-dp", action="store_true",
+                    help="with N > 1, skip the extra data-parallel (N replicas) measurement")
     args = ap.parse_args()
 
+    if os.environ.get("MINIVLLM_HANG_DUMP"):     # debugging aid: dump all stacks if stuck
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["MINIVLLM_HANG_DUMP"]), repeat=False)
     rank, local_rank, world = env_rank_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
                      "(one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ["MINIVLLM_KEEP_PG"] = "1"     # two engines in a row share one process group
 
     main_res = bench_model(args, args.model, rank, world)
     second = None
     if args.second_model and args.second_model != args.model:
         second = bench_model(args, args.second_model, rank, world)
+    dp = None
+    if world > 1 and not args.no_dp:
+        # same GPUs as N independent replicas (each serves its own batch of B sequences)
+        dp = bench_model(args, args.model, rank, world, replicas=True)
     if rank != 0:
         return
     value = main_res.get("decode_tok_s", main_res.get("prefill_tok_s"))
@@ -167,6 +199,12 @@ def main():
                    **({"layers_override": args.layers} if args.layers else {})},
         **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in main_res.items()},
     }
+    if dp is not None:
+        out["data_parallel_replicas"] = {
+            "parallelism": f"dp{world}", "scaling": "weak", "global_batch": args.batch * world,
+            "decode_tok_s": round(dp.get("decode_tok_s", 0.0) * world, 1),
+            "prefill_tok_s": round(dp.get("prefill_tok_s", 0.0) * world, 1),
+            "decode_ms_per_step": round(dp.get("decode_ms_per_step", 0.0), 3)}
     if second is not None:
         out["secondary"] = {"model": args.second_model,
                             **{k: (round(v, 3) if isinstance(v, float) else v)

@@ -495,9 +495,7 @@ class ModelRunner:
             if self.world_size == 1:
                 return idx
             pair = torch.stack([vals, idx.to(torch.float32)], dim=-1)          # [B, 2]
-            allp = [torch.empty_like(pair) for _ in range(self.world_size)]
-            torch.distributed.all_gather(allp, pair, group=pg.tp_group())
-            allp = torch.stack(allp)                                            # [tp, B, 2]
+            allp = pg.tp_all_gather_stack(pair)                                 # [tp, B, 2]
             best = allp[..., 0].argmax(dim=0)
             return allp[..., 1].gather(0, best[None]).squeeze(0).to(torch.int32)
         logits = self.model.compute_logits(hidden)
@@ -507,24 +505,18 @@ class ModelRunner:
 
     # ================================================================ graphs
     def _capture_graphs_or_fall_back(self) -> None:
-        """Graph capture must succeed on every rank or on none: a rank replaying a graph
-        while another runs eagerly would issue different collective sequences."""
-        ok = 1
-        try:
-            self.capture_graphs()
-        except Exception as e:            # e.g. a collective backend that cannot be captured
-            ok = 0
-            print(f"[rank {self.rank}] hipGraph capture failed ({type(e).__name__}: {e}); "
-                  f"decoding eagerly", flush=True)
-        if self.world_size > 1:
-            t = torch.tensor([ok], dtype=torch.int32, device=self.device)
-            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN, group=pg.tp_group())
-            ok = int(t.item())
-        if not ok:
-            self.graphs.clear()
-            self._graph_out = {}
-            self.graph_pool = None
+        """hipGraph capture needs collectives that run as stream work (RCCL does).  A backend
+        that stages through the host (gloo with GPU tensors, used only to rehearse the TP path
+        on one device) synchronises inside every collective, which a capturing stream forbids
+        and which leaves the stream unusable afterwards, so it is not even attempted there;
+        every rank takes the same decision because the backend is a property of the group."""
+        if pg.host_staged_collectives():
+            if self.rank == 0:
+                print("[runner] collectives are host-staged: decode runs eagerly (no hipGraph)",
+                      flush=True)
             self.enforce_eager = True
+            return
+        self.capture_graphs()
 
     @torch.inference_mode()
     def capture_graphs(self) -> None:

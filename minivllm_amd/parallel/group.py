@@ -21,6 +21,10 @@ _TP_RANK = 0
 _TP_SIZE = 1
 _TP_GROUP: Optional[dist.ProcessGroup] = None
 _OWNS_DEFAULT_GROUP = False
+# gloo moves GPU tensors through host memory on its own streams; when several ranks share one
+# device (single-GPU rehearsals of the TP path) queued kernels of one rank can starve the other
+# rank's copies, so the device is drained before every collective.  Never set with RCCL.
+_HOST_STAGED = False
 
 
 def tp_rank() -> int:
@@ -39,18 +43,28 @@ def is_initialized() -> bool:
     return _TP_SIZE > 1 and _TP_GROUP is not None
 
 
+def host_staged_collectives() -> bool:
+    return _HOST_STAGED
+
+
+def _drain(x: torch.Tensor) -> None:
+    if _HOST_STAGED and x.is_cuda:
+        torch.cuda.synchronize()
+
+
 def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
                          master_addr: str = "127.0.0.1", master_port: int = 29512,
                          device: Optional[torch.device] = None,
                          timeout_s: float = 600.0) -> None:
     """Join the TP group.  Reuses an already initialised default group (torchrun)."""
-    global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP
+    global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP, _HOST_STAGED
     _TP_RANK, _TP_SIZE = rank, world_size
     if world_size == 1:
         _TP_GROUP = None
         return
+    on_gpu = device is not None and torch.device(device).type == "cuda"
     if backend == "auto":
-        backend = "nccl" if (device is not None and torch.device(device).type == "cuda") else "gloo"
+        backend = "nccl" if on_gpu else "gloo"
     if not dist.is_initialized():
         kwargs = {}
         if backend == "nccl" and device is not None:
@@ -67,6 +81,7 @@ def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
     else:
         assert dist.get_world_size() == world_size and dist.get_rank() == rank
     _TP_GROUP = dist.group.WORLD
+    _HOST_STAGED = on_gpu and dist.get_backend(_TP_GROUP) == "gloo"
 
 
 def set_tp_for_testing(rank: int, world_size: int) -> None:
@@ -82,6 +97,8 @@ def destroy_tensor_parallel() -> None:
     if _TP_GROUP is not None and _OWNS_DEFAULT_GROUP and dist.is_initialized() and not keep:
         dist.destroy_process_group()
     _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP = 0, 1, None, False
+    global _HOST_STAGED
+    _HOST_STAGED = False
 
 
 # ------------------------------------------------------------- collectives
@@ -89,6 +106,7 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over the TP group; returns ``x`` (the reference returns the
     collective's return value instead of the tensor: layers/linear.py:218-219)."""
     if _TP_GROUP is not None:
+        _drain(x)
         dist.all_reduce(x, group=_TP_GROUP)
     return x
 
@@ -97,8 +115,19 @@ def tp_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
     if _TP_GROUP is None:
         return x
     parts: List[torch.Tensor] = [torch.empty_like(x) for _ in range(_TP_SIZE)]
+    _drain(x)
     dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)
     return torch.cat(parts, dim=dim)
+
+
+def tp_all_gather_stack(x: torch.Tensor) -> torch.Tensor:
+    """[tp, *x.shape]: every rank's ``x`` stacked along a new leading dim."""
+    if _TP_GROUP is None:
+        return x.unsqueeze(0)
+    parts: List[torch.Tensor] = [torch.empty_like(x) for _ in range(_TP_SIZE)]
+    _drain(x)
+    dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)
+    return torch.stack(parts)
 
 
 def tp_gather(x: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Tensor]:
@@ -108,6 +137,7 @@ def tp_gather(x: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Te
         return x
     x = x.contiguous()
     parts = [torch.empty_like(x) for _ in range(_TP_SIZE)] if _TP_RANK == dst else None
+    _drain(x)
     dist.gather(x, parts, dst=dst, group=_TP_GROUP)
     return torch.cat(parts, dim=dim) if parts is not None else None
 

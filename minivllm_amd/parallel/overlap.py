@@ -42,10 +42,8 @@ def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
         return F.linear(x, weight, bias)
     T = x.shape[0] if x.dim() == 2 else 0
     n = plan_chunks(T) if num_chunks is None else num_chunks
-    if n <= 1 or x.dim() != 2:
-        y = F.linear(x, weight, bias)
-        dist.all_reduce(y, group=group)
-        return y
+    if n <= 1 or x.dim() != 2 or pg.host_staged_collectives():
+        return pg.tp_all_reduce(F.linear(x, weight, bias))
     out = torch.empty((T, weight.shape[0]), dtype=x.dtype, device=x.device)
     works = []
     bounds = [T * i // n for i in range(n + 1)]
