@@ -126,6 +126,7 @@ class EngineConfig:
     # decode graphs
     graph_batch_sizes: Optional[list] = None
     log_stats: bool = False
+    tuned_gemms: bool = True           # load the shipped TunableOp table for library GEMMs
     checkpoint_path: Optional[str] = None
 
     # --- derived ---------------------------------------------------------

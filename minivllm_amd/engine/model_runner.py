@@ -94,6 +94,10 @@ class ModelRunner:
         pg.init_tensor_parallel(rank, cfg.world_size, cfg.dist_backend, cfg.master_addr,
                                 cfg.master_port, self.device)
 
+        if self.on_gpu and cfg.tuned_gemms:
+            from minivllm_amd.utils.gemm_tuning import enable_tuned_gemms
+            enable_tuned_gemms()
+
         # ---- model shard -------------------------------------------------
         prev = torch.get_default_dtype()
         torch.set_default_dtype(self.dtype)
