@@ -4,10 +4,9 @@ metrics (reference: benchmark_prefilling.py:294-502): O(N^2) PyTorch attention v
 full-matrix "naive" fused attention vs flash attention, fp16, Hq=32 Hkv=8 D=128, plus the
 crossover sweep and the launch-count arithmetic.
 
-The flash kernel is the hand-written gfx950 MFMA kernel of ``minivllm_amd``.  The reference's
-"naive Triton" arm (one program materialising a whole <=128-token score matrix in on-chip
-memory) has no separate kernel here: the same HIP kernel covers short sequences in one KV
-tile, so that arm is timed as PyTorch's fused SDPA on the padded batch for comparison.
+The flash kernel is the hand-written gfx950 MFMA kernel of ``minivllm_amd``; the "naive" arm is
+a deliberately simple HIP kernel that materialises the whole score matrix of a sequence in LDS
+(sequences of at most 128 tokens), the counterpart of the reference's naive Triton kernel.
 Outputs are checked against the PyTorch oracle; ``--json FILE`` dumps the timings.
 """
 import argparse
@@ -35,15 +34,14 @@ def flash_attention(q, k, v, cu_seqlens, scale, num_heads, num_kv_heads, head_di
 
 def naive_triton_attention(q, k, v, cu_seqlens, scale, num_heads, num_kv_heads, head_dim,
                            max_seq_len):
-    """Full-matrix fused attention on equal-length sequences (comparison arm)."""
-    B = cu_seqlens.numel() - 1
-    L = q.shape[0] // B
-    g = num_heads // num_kv_heads
-    qq = q.view(B, L, num_heads, head_dim).transpose(1, 2)
-    kk = k.view(B, L, num_kv_heads, head_dim).transpose(1, 2).repeat_interleave(g, dim=1)
-    vv = v.view(B, L, num_kv_heads, head_dim).transpose(1, 2).repeat_interleave(g, dim=1)
-    o = torch.nn.functional.scaled_dot_product_attention(qq, kk, vv, is_causal=True, scale=scale)
-    return o.transpose(1, 2).reshape(B * L, num_heads, head_dim)
+    """Full-matrix attention: one workgroup per (sequence, head) holds the whole score matrix in
+    LDS (HIP kernel ``attn_naive.hip``; the reference's counterpart is its naive Triton kernel).
+    Name kept from the reference script."""
+    from minivllm_amd.ops import hip
+    return hip.naive_attention(q, k, v, cu_seqlens, scale, max_seq_len)
+
+
+naive_attention = naive_triton_attention
 
 
 def setup_data(num_seqs, seq_len, num_heads, num_kv_heads, head_dim, dtype=torch.float16):
@@ -78,14 +76,14 @@ def benchmark(num_seqs, seq_len, num_heads=32, num_kv_heads=8, head_dim=128, num
     t, outputs["pytorch"] = _time(pytorch_standard_attention, args, 5, num_iter)
     results["PyTorch (O(N²))"] = t
     print(f"      {t * 1000:.3f} ms")
-    max_safe_seq = 64 if head_dim > 64 else 128
+    max_safe_seq = 128
     if seq_len <= max_safe_seq:
-        print("\n[2/3] Naive fused (O(N²), materializes full attention)...")
+        print("\n[2/3] Naive HIP (O(N²), materializes full attention)...")
         t, outputs["naive"] = _time(naive_triton_attention, args + (seq_len,), 5, num_iter)
-        results["Naive fused (O(N²))"] = t
+        results["Naive HIP (O(N²))"] = t
         print(f"      {t * 1000:.3f} ms")
     else:
-        print(f"\n[2/3] Naive fused: SKIPPED (seq_len={seq_len} > {max_safe_seq})")
+        print(f"\n[2/3] Naive HIP: SKIPPED (seq_len={seq_len} > {max_safe_seq}, score matrix would not fit LDS)")
     print("\n[3/3] Flash Attention (O(N), online softmax, gfx950 MFMA)...")
     t, outputs["flash"] = _time(flash_attention, args, 5, num_iter)
     results["Flash Attention (O(N))"] = t
@@ -106,14 +104,20 @@ def find_crossover_point():
     for L in [16, 32, 48, 64, 80, 96, 112, 128, 192, 256, 512, 1024]:
         q, k, v, cu, scale = setup_data(B, L, H, HKV, D)
         args = (q, k, v, cu, scale, H, HKV, D)
-        naive, _ = _time(naive_triton_attention, args + (L,), 10, 50)
+        naive = _time(naive_triton_attention, args + (L,), 10, 50)[0] if L <= 128 else None
         flash, _ = _time(flash_attention, args, 10, 50)
         rows.append((L, naive, flash))
-        w = "Flash" if flash < naive else "Naive"
-        print(f"  seq_len={L:5d}  Naive: {naive * 1000:.3f}ms | Flash: {flash * 1000:.3f}ms | Winner: {w}")
+        if naive is None:
+            print(f"  seq_len={L:5d}  Naive: SKIPPED | Flash: {flash * 1000:.3f}ms | Winner: Flash (by default)")
+        else:
+            w = "Flash" if flash < naive else "Naive"
+            print(f"  seq_len={L:5d}  Naive: {naive * 1000:.3f}ms | Flash: {flash * 1000:.3f}ms | Winner: {w}")
     print(f"\n{'Seq Len':>10} | {'Naive (ms)':>12} | {'Flash (ms)':>12} | {'Winner':>10} | {'Speedup':>10}")
     print("-" * 80)
     for L, n, f in rows:
+        if n is None:
+            print(f"{L:>10} | {'n/a':>12} | {f * 1000:>12.3f} | {'Flash':>10} | {'N/A':>10}")
+            continue
         w = "Flash" if f < n else "Naive"
         print(f"{L:>10} | {n * 1000:>12.3f} | {f * 1000:>12.3f} | {w:>10} | {max(n, f) / min(n, f):>9.2f}x")
     return rows
@@ -146,8 +150,8 @@ if __name__ == "__main__":
         allres.append({"num_seqs": n, "seq_len": L, **{k: v * 1e3 for k, v in r.items()}})
     if not a.no_sweep:
         sweep = find_crossover_point()
-        allres.append({"crossover": [{"seq_len": L, "naive_ms": n * 1e3, "flash_ms": f * 1e3}
-                                     for L, n, f in sweep]})
+        allres.append({"crossover": [{"seq_len": L, "naive_ms": None if n is None else n * 1e3,
+                                      "flash_ms": f * 1e3} for L, n, f in sweep]})
     analyze_kernel_launches()
     if a.json:
         Path(a.json).write_text(json.dumps(allres, indent=1))

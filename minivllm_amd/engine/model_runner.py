@@ -51,13 +51,14 @@ class Batch:
     max_context_len: int = 0
     has_prefix: bool = False
     step: int = 0
+    tables_unchanged: bool = False      # decode: block tables equal the previous step's
     arrays: Dict[str, np.ndarray] = field(default_factory=dict)
 
     def scalars(self) -> dict:
         return dict(is_prefill=self.is_prefill, num_seqs=self.num_seqs, num_tokens=self.num_tokens,
                     max_seqlen_q=self.max_seqlen_q, max_seqlen_k=self.max_seqlen_k,
                     max_context_len=self.max_context_len, has_prefix=self.has_prefix,
-                    step=self.step)
+                    step=self.step, tables_unchanged=self.tables_unchanged)
 
 
 def default_graph_batch_sizes(max_bs: int) -> List[int]:
@@ -114,6 +115,10 @@ class ModelRunner:
             self.model.init_random_weights(cfg.seed)
         self.sampler = SamplerLayer(seed=cfg.seed)
         self.step_counter = 0
+        self._decode_prev = None          # (batch list object, arrays) of the last decode step
+        self._last_tokens: Optional[List[int]] = None
+        self._arange_cache = np.arange(256)
+        self._dec_tables_key = None       # (padded batch, num_seqs) the host table image holds
         self.graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
         self.graph_pool = None
         self.kv_cache: Optional[torch.Tensor] = None
@@ -349,6 +354,23 @@ class ModelRunner:
     def prepare_decode(self, seqs: Seq[Sequence]) -> Batch:
         bs = self.block_size
         B = len(seqs)
+        prev = self._decode_prev
+        if prev is not None and prev[0] is seqs and self._last_tokens is not None \
+                and len(self._last_tokens) == B:
+            # the scheduler handed back the very same batch (steady-state decode: every
+            # sequence grew by the token sampled last step, no block table changed)
+            a = prev[1]
+            lens = a["context_lens"] + 1
+            pos = lens - 1
+            tables = a["block_tables"]
+            blk = tables[self._arange(B), pos // bs]
+            arrays = dict(input_ids=np.asarray(self._last_tokens, dtype=np.int32), positions=pos,
+                          slot_mapping=blk * bs + pos % bs, context_lens=lens,
+                          temperatures=a["temperatures"], block_tables=tables)
+            self._decode_prev = (seqs, arrays)
+            m = int(lens.max())
+            return Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1, max_seqlen_k=m,
+                         max_context_len=m, arrays=arrays, tables_unchanged=True)
         lens = np.fromiter((s.num_tokens for s in seqs), np.int32, B)
         last_block = np.fromiter((s.block_table[-1] for s in seqs), np.int32, B)
         MB = max(len(s.block_table) for s in seqs)
@@ -356,13 +378,18 @@ class ModelRunner:
         for i, s in enumerate(seqs):
             tables[i, :len(s.block_table)] = s.block_table
         pos = lens - 1
+        arrays = dict(input_ids=np.fromiter((s.last_token for s in seqs), np.int32, B),
+                      positions=pos, slot_mapping=last_block * bs + pos % bs, context_lens=lens,
+                      temperatures=np.fromiter((s.temperature for s in seqs), np.float32, B),
+                      block_tables=tables)
+        self._decode_prev = (seqs, arrays)
         return Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1,
-                     max_seqlen_k=int(lens.max()), max_context_len=int(lens.max()),
-                     arrays=dict(input_ids=np.fromiter((s.last_token for s in seqs), np.int32, B),
-                                 positions=pos, slot_mapping=last_block * bs + pos % bs,
-                                 context_lens=lens,
-                                 temperatures=np.fromiter((s.temperature for s in seqs), np.float32, B),
-                                 block_tables=tables))
+                     max_seqlen_k=int(lens.max()), max_context_len=int(lens.max()), arrays=arrays)
+
+    def _arange(self, n: int) -> np.ndarray:
+        if self._arange_cache.size < n:
+            self._arange_cache = np.arange(max(n, 256))
+        return self._arange_cache[:n]
 
     def prepare_sample(self, seqs: Seq[Sequence]) -> torch.Tensor:
         return torch.tensor([s.temperature for s in seqs], dtype=torch.float32, device=self.device)
@@ -370,7 +397,11 @@ class ModelRunner:
     # ================================================================== run
     def run(self, seqs: Seq[Sequence], is_prefill: bool) -> Optional[List[int]]:
         """Rank 0 entry point for one step; returns the sampled token per sequence."""
-        batch = self.prepare_prefill(seqs) if is_prefill else self.prepare_decode(seqs)
+        if is_prefill:
+            self._decode_prev = None
+            batch = self.prepare_prefill(seqs)
+        else:
+            batch = self.prepare_decode(seqs)
         self.step_counter += 1
         batch.step = self.step_counter
         if self.world_size > 1 and self.rank == 0:
@@ -424,6 +455,10 @@ class ModelRunner:
         put("context_lens", a["context_lens"], 0)
         put("temperatures", a["temperatures"].astype(np.float32).view(np.int32), 0)
         host[self._dec_off["misc"][0]] = b.step
+        key = (padded_bs, B)
+        if b.tables_unchanged and self._dec_tables_key == key:
+            return                        # the table image already holds these rows
+        self._dec_tables_key = key
         off, _ = self._dec_off["block_tables"]
         tab = host[off:off + padded_bs * MBmax].reshape(padded_bs, MBmax)
         mb = a["block_tables"].shape[1]
@@ -473,7 +508,9 @@ class ModelRunner:
         reset_context()
         if warmup or tokens is None or self.rank != 0:
             return None
-        return tokens.tolist()
+        out = tokens.tolist()
+        self._last_tokens = None if b.is_prefill else out
+        return out
 
     def _graph_bucket(self, B: int) -> Optional[int]:
         if not self.graphs:

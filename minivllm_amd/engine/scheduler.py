@@ -32,6 +32,12 @@ class Scheduler:
         self.waiting: Deque[Sequence] = deque()
         self.running: Deque[Sequence] = deque()
         self.num_preemptions = 0
+        # steady-state decode shortcut: while no running sequence touches a block boundary
+        # (no allocation, no hash to publish) and membership is unchanged, the previous decode
+        # batch is simply scheduled again (same list object, which also tells the runner that
+        # it may update its batch arrays incrementally)
+        self._decode_batch: Optional[List[Sequence]] = None
+        self._plain_decode_steps = 0
 
     def is_finished(self) -> bool:
         return not self.waiting and not self.running
@@ -54,6 +60,7 @@ class Scheduler:
             raise ValueError(
                 f"request needs {need} KV blocks but the cache has {self.block_manager.num_blocks}")
         self.waiting.append(seq)
+        self._decode_batch = None
 
     # ------------------------------------------------------------- schedule
     def schedule(self) -> Tuple[List[Sequence], bool]:
@@ -82,9 +89,14 @@ class Scheduler:
             scheduled.append(seq)
             num_tokens += len(seq) - seq.num_cached_tokens
         if scheduled:
+            self._decode_batch = None
             return scheduled, True
 
         # phase 2: one token for every running sequence, oldest first
+        if (self._decode_batch is not None and self._plain_decode_steps > 0 and not self.waiting
+                and self._decode_batch):
+            self._plain_decode_steps -= 1
+            return self._decode_batch, False
         candidates = self.running
         self.running = deque()
         deferred: List[Sequence] = []
@@ -110,9 +122,21 @@ class Scheduler:
             num_tokens += 1
         self.running.extend(scheduled)
         self.running.extend(deferred)
+        if scheduled and not deferred and not self.waiting:
+            bs = self.block_size
+            # after this step a sequence holds n + 1 tokens; the step scheduled for length m
+            # is plain unless m % bs is 0 (publishes a hash) or 1 (needs a new block)
+            plain = bs
+            for seq in scheduled:
+                r = (seq.num_tokens + 1) % bs
+                plain = min(plain, 0 if r <= 1 else bs - r)
+            self._decode_batch, self._plain_decode_steps = scheduled, (plain if bs > 2 else 0)
+        else:
+            self._decode_batch = None
         return scheduled, False
 
     def preempt(self, seq: Sequence) -> None:
+        self._decode_batch = None
         self.block_manager.deallocate(seq)
         seq.status = SequenceStatus.WAITING
         self.waiting.appendleft(seq)
@@ -132,6 +156,7 @@ class Scheduler:
                 self.block_manager.deallocate(seq)
                 finished.append(seq)
         if finished:
+            self._decode_batch = None
             done = {id(s) for s in finished}
             self.running = deque(s for s in self.running if id(s) not in done)
         return finished

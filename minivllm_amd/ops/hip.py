@@ -54,6 +54,10 @@ _prefill = _sig("mvl_flash_attention_prefill", _c_void, _c_long, _c_long, _c_voi
                 _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
                 _c_void)
 
+_naive = _sig("mvl_naive_attention", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long, _c_long,
+              _c_void, _c_long, _c_long, _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
+              _c_int, _c_void)
+
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 
 
@@ -199,6 +203,27 @@ def flash_attention_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                     out.data_ptr(), out.stride(0), out.stride(1), cu.data_ptr(), cu.data_ptr(),
                     None, 0, 1, scale, cu.numel() - 1, hq, hkv, d, max_seqlen, 0, _dt(q),
                     _stream()), "flash_attention_prefill")
+    return out
+
+
+NAIVE_ATTENTION_MAX_LEN = 128
+
+
+def naive_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlens: torch.Tensor,
+                    scale: float, max_seqlen: int) -> torch.Tensor:
+    """Full-matrix causal attention for sequences of at most 128 tokens (benchmark baseline)."""
+    if max_seqlen > NAIVE_ATTENTION_MAX_LEN:
+        raise ValueError(f"naive attention holds the score matrix in LDS: seq_len <= "
+                         f"{NAIVE_ATTENTION_MAX_LEN}, got {max_seqlen}")
+    T, hq, d = q.shape
+    cu = _i32(cu_seqlens)
+    qs_t, qs_h = _q_strides(q)
+    ks_t, ks_h = _q_strides(k)
+    assert _q_strides(v) == (ks_t, ks_h)
+    out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    _check(_naive(q.data_ptr(), qs_t, qs_h, k.data_ptr(), v.data_ptr(), ks_t, ks_h, out.data_ptr(),
+                  out.stride(0), out.stride(1), cu.data_ptr(), scale, cu.numel() - 1, hq,
+                  k.shape[1], d, max_seqlen, _dt(q), _stream()), "naive_attention")
     return out
 
 

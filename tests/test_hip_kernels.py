@@ -291,3 +291,20 @@ def test_decode_matches_prefill_last_row(hip):
     dec = hip.paged_attention_decode(q[-1:].contiguous(), kc, vc, tables,
                                      torch.tensor([L], device=DEV, dtype=torch.int32), 0.0884)
     close(dec[0], pre[-1], dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (4, 4, 64)])
+def test_naive_attention_baseline(hip, dtype, hq, hkv, d):
+    torch.manual_seed(15)
+    lens = [1, 60, 128, 17]
+    T = sum(lens)
+    q = torch.randn(T, hq, d, device=DEV, dtype=dtype)
+    k = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    want = ref.flash_attention_prefill(q, k, v, cu, 1 / math.sqrt(d))
+    got = hip.naive_attention(q, k, v, cu, 1 / math.sqrt(d), 128)
+    close(got, want, dtype)
+    with pytest.raises(ValueError):
+        hip.naive_attention(q, k, v, cu, 0.1, 129)
