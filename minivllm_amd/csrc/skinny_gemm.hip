@@ -1,0 +1,148 @@
+// Weight-streaming GEMM for decode-sized inputs:  out[M, N] = x[M, K] . W[N, K]^T,  M <= 16.
+//
+// At these sizes a projection is a pure stream of the weight matrix (every weight byte is
+// used once, 2 M flops per byte), so the kernel is organised like the paged-decode attention
+// kernel: keep as many 16-byte-per-lane loads in flight as the CU allows and let MFMA
+// 16x16x32 do the (nearly free) arithmetic.
+//
+//  * one workgroup per 16-column tile of the output; its waves split K, so the whole chip is
+//    busy even for N = 4096 (256 tiles x up to 16 waves) and the split-K reduction stays
+//    inside the workgroup (LDS), never across workgroups;
+//  * W is the MFMA B operand straight from global memory: lane (n = lane & 15, q = lane >> 4)
+//    holds W[n0 + n][k + 8 q .. +7], i.e. 16 contiguous bytes, 64 contiguous bytes per row and
+//    instruction; the loop is unrolled 8 deep so each row is read in 512-byte bursts;
+//  * x (at most 16 rows, L2 resident) is the A operand, loaded the same way; rows >= M are
+//    clamped duplicates whose results are dropped;
+//  * epilogues: plain (+ optional bias), or SwiGLU: the tile computes the gate and the up
+//    projection of the same 16 columns (rows n and I + n of the fused weight) with one shared
+//    x fragment and stores silu(gate) * up, which removes the activation kernel and the
+//    [M, 2I] intermediate.
+#include "common.h"
+
+using namespace mvl;
+
+namespace {
+
+constexpr int kUnroll = 8;
+
+template <int CODE, int EPI, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
+        const uint16_t* __restrict__ x, long x_stride, const uint16_t* __restrict__ w,
+        const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, long o_stride, int M,
+        int K, int up_row_offset) {
+    using DT = DType<CODE>;
+    using vec8 = typename DT::vec8;
+    constexpr int NB = EPI == 1 ? 2 : 1;
+    __shared__ float red[WAVES][NB][16][17];
+
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c16 = lane & 15, q4 = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int kslice = K / WAVES;
+    const long koff = (long)wv * kslice + 8 * q4;
+    const uint16_t* wp0 = w + (long)(n0 + c16) * K + koff;
+    const uint16_t* wp1 = w + (long)(up_row_offset + n0 + c16) * K + koff;
+    const uint16_t* xp = x + (long)min(c16, M - 1) * x_stride + koff;
+
+    f32x4_t acc[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+    int k = 0;
+    for (; k + 32 * kUnroll <= kslice; k += 32 * kUnroll) {
+        u32x4_t bw[NB][kUnroll], ax[kUnroll];
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            bw[0][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp0 + k + 32 * u));
+            if (NB == 2)
+                bw[NB - 1][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp1 + k + 32 * u));
+            ax[u] = *reinterpret_cast<const u32x4_t*>(xp + k + 32 * u);
+        }
+        // all loads of the block are issued before the first MFMA waits for one of them
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) {
+            const vec8 a = __builtin_bit_cast(vec8, ax[u]);
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+                acc[b] = DT::mfma16(a, __builtin_bit_cast(vec8, bw[b][u]), acc[b]);
+        }
+    }
+    for (; k < kslice; k += 32) {
+        const vec8 a = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(xp + k));
+        acc[0] = DT::mfma16(a, __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(wp0 + k)), acc[0]);
+        if (NB == 2)
+            acc[NB - 1] = DT::mfma16(a, __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(wp1 + k)),
+                                     acc[NB - 1]);
+    }
+
+    // split-K reduction across the waves; accumulator layout: col n = lane & 15, row m = 4 q + r
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wv][b][4 * q4 + r][c16] = acc[b][r];
+    __syncthreads();
+    if (threadIdx.x < 256) {
+        const int m = threadIdx.x >> 4, n = threadIdx.x & 15;
+        if (m < M) {
+            float s[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                s[b] = 0.f;
+#pragma unroll
+                for (int ww = 0; ww < WAVES; ++ww) s[b] += red[ww][b][m][n];
+            }
+            float r;
+            if (EPI == 1) {
+                if (bias != nullptr) {
+                    s[0] += DT::to_float(bias[n0 + n]);
+                    s[NB - 1] += DT::to_float(bias[up_row_offset + n0 + n]);
+                }
+                r = s[0] / (1.f + __expf(-s[0])) * s[NB - 1];
+            } else {
+                r = s[0] + (bias != nullptr ? DT::to_float(bias[n0 + n]) : 0.f);
+            }
+            out[(long)m * o_stride + n0 + n] = DT::from_float(r);
+        }
+    }
+}
+
+template <int CODE, int EPI>
+int launch(const void* x, long xs, const void* w, const void* bias, void* out, long os, int M,
+           int N_out, int K, int up_off, hipStream_t st) {
+    // waves per workgroup = K splits; keep >= 4 k-steps per wave
+    const int tiles = N_out / 16;
+    auto X = (const uint16_t*)x; auto W = (const uint16_t*)w; auto B = (const uint16_t*)bias;
+    auto O = (uint16_t*)out;
+    if (K % (16 * 32) == 0 && K / 16 >= 128)
+        skinny_gemm_kernel<CODE, EPI, 16><<<tiles, 16 * 64, 0, st>>>(X, xs, W, B, O, os, M, K, up_off);
+    else if (K % (8 * 32) == 0 && K / 8 >= 128)
+        skinny_gemm_kernel<CODE, EPI, 8><<<tiles, 8 * 64, 0, st>>>(X, xs, W, B, O, os, M, K, up_off);
+    else if (K % (4 * 32) == 0)
+        skinny_gemm_kernel<CODE, EPI, 4><<<tiles, 4 * 64, 0, st>>>(X, xs, W, B, O, os, M, K, up_off);
+    else
+        return -1;
+    return MVL_CHECK_LAUNCH();
+}
+
+}  // namespace
+
+// epilogue 0: out[M, N] = x . W^T (+ bias);  W is [N, K] row-major, N % 16 == 0.
+// epilogue 1: W is [2 I, K] (gate rows then up rows), out[M, I] = silu(x.Wg^T) * (x.Wu^T).
+extern "C" int mvl_skinny_gemm(const void* x, long x_stride, const void* w, const void* bias,
+                               void* out, long o_stride, int M, int N, int K, int epilogue,
+                               int dtype, void* stream) {
+    if (M == 0) return 0;
+    if (M > 16 || K % 128 != 0) return -1;
+    auto st = (hipStream_t)stream;
+    if (epilogue == 0) {
+        if (N % 16 != 0) return -1;
+        return dtype == 0 ? launch<0, 0>(x, x_stride, w, bias, out, o_stride, M, N, K, 0, st)
+                          : launch<1, 0>(x, x_stride, w, bias, out, o_stride, M, N, K, 0, st);
+    }
+    if (N % 32 != 0) return -1;
+    const int inter = N / 2;
+    return dtype == 0 ? launch<0, 1>(x, x_stride, w, bias, out, o_stride, M, inter, K, inter, st)
+                      : launch<1, 1>(x, x_stride, w, bias, out, o_stride, M, inter, K, inter, st);
+}

@@ -587,7 +587,9 @@ class ModelRunner:
             step()                                   # warm-up outside capture
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graph_pool):
+            # thread-local capture: RCCL's watchdog thread may query events while this thread
+            # captures, which the default (global) mode would turn into a capture error
+            with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
                 out = step()
             if self.graph_pool is None:
                 self.graph_pool = g.pool()

@@ -9,7 +9,9 @@ column-parallel loader narrows by the shard *length* (the reference passes
 tensor (the reference returns the collective's return value), and bias is added
 on rank 0 only before the reduction.
 
-The GEMMs themselves are plain library calls (hipBLASLt through ``F.linear``).
+The GEMMs are library calls (hipBLASLt through ``F.linear``) except for decode-sized inputs
+of the shapes where the weight-streaming kernel of ``csrc/skinny_gemm.hip`` is faster
+(``ops.linear`` / ``ops.swiglu_linear`` decide).
 """
 from __future__ import annotations
 
@@ -19,6 +21,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from minivllm_amd import ops
 from minivllm_amd.parallel import group as pg
 
 
@@ -75,7 +78,7 @@ class ColumnParallelLinear(LinearBase):
         param.data.copy_(loaded_weight.narrow(0, self.tp_rank * shard, shard))
 
     def forward(self, x):
-        return F.linear(x, self.weight, self.bias)
+        return ops.linear(x, self.weight, self.bias)
 
 
 class MergedColumnParallelLinear(ColumnParallelLinear):
@@ -92,6 +95,12 @@ class MergedColumnParallelLinear(ColumnParallelLinear):
         size = self.output_sizes[loaded_weight_id] // self.tp_size
         dst = param.data.narrow(0, off, size)
         dst.copy_(loaded_weight.narrow(0, self.tp_rank * size, size))
+
+    def forward_swiglu(self, x):
+        """``silu(gate(x)) * up(x)`` for a fused [gate; up] pair, without materialising the
+        [T, 2I] GEMM output when the fused decode kernel applies."""
+        assert len(self.output_sizes) == 2 and self.output_sizes[0] == self.output_sizes[1]
+        return ops.swiglu_linear(x, self.weight, self.bias)
 
 
 class QKVColumnParallelLinear(ColumnParallelLinear):
@@ -146,4 +155,4 @@ class RowParallelLinear(LinearBase):
         if self.tp_size > 1 and self.reduce_results:
             from minivllm_amd.parallel.overlap import row_parallel_linear
             return row_parallel_linear(x, self.weight, bias)
-        return F.linear(x, self.weight, bias)
+        return ops.linear(x, self.weight, bias)

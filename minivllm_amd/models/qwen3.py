@@ -81,7 +81,7 @@ class Qwen3MLP(nn.Module):
         self.act_fn = SiluAndMul()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return self.down_proj(self.act_fn(self.gate_up_proj(x)))
+        return self.down_proj(self.gate_up_proj.forward_swiglu(x))
 
 
 class Qwen3DecoderLayer(nn.Module):

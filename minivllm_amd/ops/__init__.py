@@ -6,6 +6,7 @@ used on CPU and as the test oracle).  A GPU tensor never falls back to
 from __future__ import annotations
 
 import torch
+import torch.nn.functional as F
 
 from . import torch_ref
 
@@ -66,6 +67,26 @@ def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scal
         return _hip().paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens,
                                              scale, max_context_len)
     return torch_ref.paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scale)
+
+
+def linear(x, weight, bias=None):
+    """``x @ weight.T (+ bias)``: the library GEMM, except for decode-sized GPU inputs of the
+    shapes where the hand-written weight-streaming kernel is faster."""
+    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 8:
+        h = _hip()
+        if h.skinny_gemm_pays(x, weight):
+            return h.skinny_linear(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+def swiglu_linear(x, weight, bias=None):
+    """``silu(x @ Wg.T) * (x @ Wu.T)`` for the fused ``[Wg; Wu]`` weight: one kernel for
+    decode-sized GPU inputs, otherwise GEMM + activation kernel."""
+    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 8:
+        h = _hip()
+        if h.skinny_gemm_pays(x, weight, swiglu=True):
+            return h.skinny_linear(x, weight, bias, swiglu=True)
+    return silu_and_mul(F.linear(x, weight, bias))
 
 
 def sample(logits, temperatures, seed=0, step=0, generator=None):

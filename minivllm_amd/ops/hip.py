@@ -58,6 +58,9 @@ _naive = _sig("mvl_naive_attention", _c_void, _c_long, _c_long, _c_void, _c_void
               _c_void, _c_long, _c_long, _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
               _c_int, _c_void)
 
+_skinny = _sig("mvl_skinny_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_int,
+               _c_int, _c_int, _c_int, _c_int, _c_void)
+
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 
 
@@ -281,6 +284,50 @@ def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torc
                    bt.data_ptr(), bt.stride(0), ctx.data_ptr(), out.data_ptr(), out.stride(0),
                    out.stride(1), pa, pm, scale, B, hq, hkv, d, k_cache.shape[1], ns, _dt(q),
                    _stream()), "paged_attention_decode")
+    return out
+
+
+# ------------------------------------------------------- weight-streaming GEMM
+SKINNY_MAX_ROWS = 16
+SKINNY_PAYS_ROWS = 8                  # up to here the kernel beats the library (see skinny_gemm_pays)
+SKINNY_MIN_WEIGHT_BYTES = 8 << 20     # below this a projection is launch-latency bound anyway
+
+
+def skinny_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
+    """Shapes the weight-streaming kernel takes: <= 16 rows, K a multiple of 128, enough
+    16-column tiles to cover the chip, weights big enough to be worth streaming by hand."""
+    if x.dim() != 2 or x.shape[0] == 0 or x.shape[0] > SKINNY_MAX_ROWS or x.dtype not in _DT:
+        return False
+    n, k = weight.shape
+    n_out = n // 2 if swiglu else n
+    return (weight.dtype == x.dtype and weight.is_contiguous() and x.stride(1) == 1
+            and k % 128 == 0 and n_out % 16 == 0 and n_out // 16 >= 192
+            and n * k * 2 >= SKINNY_MIN_WEIGHT_BYTES)
+
+
+def skinny_gemm_pays(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
+    """Whether the weight-streaming kernel is the faster choice for this call.  Measured against
+    the tuned library GEMM on MI355X (Qwen3-8B shapes, graph replay, tools/skinny_gemm_bench.py):
+    with <= 8 rows the fused SwiGLU form wins (one kernel instead of GEMM + activation, 40.8 vs
+    45.2 us at 1 row), and so does the plain form when the grid is a single round of workgroups
+    that each make one pass over K (N <= 4096, K <= 4096: 9.8 vs 12.0 us); longer K or more
+    column tiles go to the library, which then streams at ~4.6 TB/s."""
+    if x.dim() != 2 or x.shape[0] > SKINNY_PAYS_ROWS or not skinny_gemm_ok(x, weight, swiglu):
+        return False
+    n, k = weight.shape
+    return swiglu or (n <= 4096 and k <= 4096)
+
+
+def skinny_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                  swiglu: bool = False) -> torch.Tensor:
+    """``x @ weight.T (+ bias)`` for <= 16 rows; with ``swiglu`` the weight is the fused
+    [gate; up] matrix and the result is ``silu(gate) * up``."""
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N // 2 if swiglu else N), dtype=x.dtype, device=x.device)
+    _check(_skinny(x.data_ptr(), x.stride(0), weight.data_ptr(),
+                   bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
+                   M, N, K, 1 if swiglu else 0, _dt(x), _stream()), "skinny_gemm")
     return out
 
 

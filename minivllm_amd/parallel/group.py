@@ -124,6 +124,11 @@ def tp_all_gather_stack(x: torch.Tensor) -> torch.Tensor:
     """[tp, *x.shape]: every rank's ``x`` stacked along a new leading dim."""
     if _TP_GROUP is None:
         return x.unsqueeze(0)
+    if not _HOST_STAGED and x.is_cuda:
+        # one output buffer, one collective, no per-rank copies (graph-capture friendly)
+        out = torch.empty((_TP_SIZE,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(out, x.contiguous(), group=_TP_GROUP)
+        return out
     parts: List[torch.Tensor] = [torch.empty_like(x) for _ in range(_TP_SIZE)]
     _drain(x)
     dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)

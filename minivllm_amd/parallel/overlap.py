@@ -20,6 +20,7 @@ import torch.distributed as dist
 import torch.nn.functional as F
 
 from . import group as pg
+from .. import ops
 
 # below this many rows per chunk the collective is latency-bound and splitting only hurts
 MIN_CHUNK_TOKENS = 2048
@@ -43,7 +44,7 @@ def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
     T = x.shape[0] if x.dim() == 2 else 0
     n = plan_chunks(T) if num_chunks is None else num_chunks
     if n <= 1 or x.dim() != 2 or pg.host_staged_collectives():
-        return pg.tp_all_reduce(F.linear(x, weight, bias))
+        return pg.tp_all_reduce(ops.linear(x, weight, bias))
     out = torch.empty((T, weight.shape[0]), dtype=x.dtype, device=x.device)
     works = []
     bounds = [T * i // n for i in range(n + 1)]

@@ -308,3 +308,31 @@ def test_naive_attention_baseline(hip, dtype, hq, hkv, d):
     close(got, want, dtype)
     with pytest.raises(ValueError):
         hip.naive_attention(q, k, v, cu, 0.1, 129)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 5, 16])
+@pytest.mark.parametrize("N,K", [(4096, 4096), (6144, 4096), (4096, 12288), (3072, 2048), (4096, 1536)])
+def test_skinny_gemm(hip, dtype, M, N, K):
+    torch.manual_seed(16)
+    x = torch.randn(M, K, device=DEV, dtype=dtype)
+    w = (torch.randn(N, K, device=DEV) * 0.05).to(dtype)
+    b = torch.randn(N, device=DEV, dtype=dtype)
+    want = x.float() @ w.float().T
+    close(hip.skinny_linear(x, w), want, dtype, 4)
+    close(hip.skinny_linear(x, w, b), want + b.float(), dtype, 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 7, 16])
+def test_skinny_gemm_swiglu(hip, dtype, M):
+    torch.manual_seed(17)
+    K, I = 4096, 12288
+    xx = torch.randn(M + 3, K + 64, device=DEV, dtype=dtype)
+    x = xx[:M, :K]                                    # strided rows
+    w = (torch.randn(2 * I, K, device=DEV) * 0.03).to(dtype)
+    y = x.float() @ w.float().T
+    want = torch.nn.functional.silu(y[:, :I]) * y[:, I:]
+    close(hip.skinny_linear(x, w, swiglu=True), want, dtype, 4)
+    assert hip.skinny_gemm_ok(x, w, swiglu=True)
+    assert not hip.skinny_gemm_ok(torch.empty(17, K, device=DEV, dtype=dtype), w)

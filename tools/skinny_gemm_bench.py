@@ -1,0 +1,39 @@
+"""Weight-streaming GEMM kernel vs the library GEMM on the decode projections of Qwen3-8B
+(graph-replayed, rotating weights so that every call streams from HBM)."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from minivllm_amd.ops import hip
+
+shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (24576, 4096), "down": (4096, 12288)}
+
+
+def bench(fn, x, ws):
+    for w in ws:
+        fn(x, w)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(5):
+            for w in ws:
+                fn(x, w)
+    g.replay(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        g.replay()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / (25 * len(ws))
+
+
+for M in (1, 8, 16):
+    for name, (N, K) in shapes.items():
+        x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
+        ws = [torch.randn(N, K, device="cuda", dtype=torch.bfloat16) for _ in range(4)]
+        tl = bench(torch.nn.functional.linear, x, ws)
+        tk = bench(hip.skinny_linear, x, ws)
+        line = f"M={M:2d} {name:8s} library {tl*1e6:6.1f} us ({N*K*2/tl/1e12:4.2f} TB/s)  kernel {tk*1e6:6.1f} us ({N*K*2/tk/1e12:4.2f} TB/s)"
+        if name == "gate_up":
+            tf = bench(lambda a, w: hip.skinny_linear(a, w, swiglu=True), x, ws)
+            tlf = bench(lambda a, w: hip.silu_and_mul(torch.nn.functional.linear(a, w)), x, ws)
+            line += f" | fused SwiGLU: library+act {tlf*1e6:6.1f} us, kernel {tf*1e6:6.1f} us"
+        print(line, flush=True)
