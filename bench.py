@@ -185,6 +185,18 @@ def main():
         dp = bench_model(args, args.model, rank, world, replicas=True)
     if rank != 0:
         return
+    published = None
+    try:
+        # the only numbers the reference publishes: SiluAndMul fp32 timings (1x A6000)
+        from benchmark_activation import PUBLISHED_A6000_MS, time_layer
+        from minivllm_amd.layers.activation import SiluAndMul
+        shape = (4000, 8000)
+        ms = time_layer(SiluAndMul(), torch.randn(*shape, device="cuda", dtype=torch.float32))
+        published = {"op": "SiluAndMul forward 4000x8000 fp32 (reference method)",
+                     "ms": round(ms, 4), "reference_a6000_ms": PUBLISHED_A6000_MS[shape],
+                     "speedup": round(PUBLISHED_A6000_MS[shape] / ms, 2)}
+    except Exception as e:                       # never lose the headline over the side check
+        published = {"error": repr(e)}
     value = main_res.get("decode_tok_s", main_res.get("prefill_tok_s"))
     ms = main_res.get("decode_ms_per_step", main_res.get("prefill_ms_per_step"))
     out = {
@@ -205,6 +217,7 @@ def main():
             "decode_tok_s": round(dp.get("decode_tok_s", 0.0) * world, 1),
             "prefill_tok_s": round(dp.get("prefill_tok_s", 0.0) * world, 1),
             "decode_ms_per_step": round(dp.get("decode_ms_per_step", 0.0), 3)}
+    out["published_reference_check"] = published
     if second is not None:
         out["secondary"] = {"model": args.second_model,
                             **{k: (round(v, 3) if isinstance(v, float) else v)

@@ -118,15 +118,42 @@ __global__ void silu_mul_kernel(const uint16_t* __restrict__ x, uint16_t* __rest
     }
 }
 
+// fp32 rows (the precision of the reference's own activation micro-benchmark,
+// reference: src/myvllm/layers/activation.py:20-37): 16 bytes = 4 elements per lane
+__global__ void silu_mul_f32_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                    long rows, int inter, long x_stride, long o_stride) {
+    const int cpr = inter >> 2;
+    const long total = rows * cpr;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / cpr;
+        const int c = (int)(idx - r * cpr);
+        const f32x4_t* xr = reinterpret_cast<const f32x4_t*>(x + r * x_stride);
+        const f32x4_t a = __builtin_nontemporal_load(xr + c);
+        const f32x4_t b = __builtin_nontemporal_load(xr + cpr + c);
+        f32x4_t o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a[j] / (1.f + __expf(-a[j])) * b[j];
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4_t*>(out + r * o_stride) + c);
+    }
+}
+
+// dtype: 0 = bf16, 1 = fp16, 2 = fp32
 extern "C" int mvl_silu_and_mul(const void* x, void* out, long rows, int inter, long x_stride,
                                 long o_stride, int dtype, void* stream) {
-    if (inter % 8 != 0) return -1;
+    if (inter % (dtype == 2 ? 4 : 8) != 0) return -1;
     if (rows == 0) return 0;
-    const long total = rows * (inter / 8);
+    const long total = rows * (inter / (dtype == 2 ? 4 : 8));
     const int threads = 256;
     long blocks = (total + threads - 1) / threads;
     if (blocks > 256 * 16) blocks = 256 * 16;
     auto st = (hipStream_t)stream;
+    if (dtype == 2) {
+        if ((x_stride | o_stride) % 4 != 0) return -1;
+        silu_mul_f32_kernel<<<(unsigned)blocks, threads, 0, st>>>((const float*)x, (float*)out, rows,
+                                                                  inter, x_stride, o_stride);
+        return MVL_CHECK_LAUNCH();
+    }
     if (dtype == 0)
         silu_mul_kernel<0><<<(unsigned)blocks, threads, 0, st>>>((const uint16_t*)x, (uint16_t*)out,
                                                                  rows, inter, x_stride, o_stride);

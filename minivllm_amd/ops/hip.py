@@ -120,7 +120,8 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
     x2, rows, xs = _rows2d(x)
     inter = x.shape[-1] // 2
     out = torch.empty((rows, inter), dtype=x.dtype, device=x.device)
-    _check(_silu(x2.data_ptr(), out.data_ptr(), rows, inter, xs, inter, _dt(x), _stream()),
+    code = 2 if x.dtype == torch.float32 else _dt(x)       # fp32 rows have their own kernel
+    _check(_silu(x2.data_ptr(), out.data_ptr(), rows, inter, xs, inter, code, _stream()),
            "silu_and_mul")
     return out.view(*x.shape[:-1], inter)
 

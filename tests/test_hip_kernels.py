@@ -58,6 +58,16 @@ def test_silu_and_mul(hip, dtype, rows, inter):
     close(hip.silu_and_mul(x), ref.silu_and_mul(x), dtype)
 
 
+@pytest.mark.parametrize("shape", [(400, 800), (3, 4000, 8000), (5, 8)])
+def test_silu_and_mul_fp32(hip, shape):
+    """fp32 rows: the precision of the reference's activation micro-benchmark."""
+    torch.manual_seed(3)
+    x = torch.randn(*shape, device=DEV, dtype=torch.float32)
+    got = hip.silu_and_mul(x)
+    assert got.dtype == torch.float32 and got.shape == (*shape[:-1], shape[-1] // 2)
+    torch.testing.assert_close(got, ref.silu_and_mul(x), atol=2e-6, rtol=2e-6)
+
+
 def _logical_cache(nb, bs, hkv, d, dtype, head_major=True):
     """[nb, bs, hkv, d] logical view; physical order head-major like the engine's."""
     if head_major:
