@@ -16,18 +16,28 @@ sum(len(prompt)) tokens, a decode step one token per running sequence.
   every engine step is a prefill step); W untimed, then exactly K timed steps.
 
 Each timed region is bracketed by device synchronise + barrier on every rank and the elapsed
-time is the MAX over ranks.  Rank 0 prints ONE JSON line; ``value`` is the whole-job decode
-tok/s of the flagship model, the prefill number and the second model are extra keys.
-With N > 1 the model is tensor-parallel over the N GPUs (RCCL over xGMI) and the global batch
-is the same as with 1 GPU (strong scaling); that is the headline ``value``.  The same N GPUs are
-then also measured as N independent single-GPU replicas (data parallel, weak scaling) and
-reported under ``data_parallel_replicas``.
+time is the MAX over ranks.  Rank 0 prints ONE JSON line.
+
+With N > 1 two deployments of the same N GPUs are measured:
+
+* data parallel (the headline ``value``): N single-GPU replicas, each serving its own batch of
+  B sequences (weak scaling, global batch N x B).  Qwen3-8B fits one 288 GB GPU many times
+  over, so the throughput-optimal MI355X deployment does not shard it: no xGMI collective sits
+  on the critical path and every GEMM keeps its full width.
+* tensor parallel (``tensor_parallel`` in the JSON): ONE engine sharded over the N GPUs (RCCL
+  all-reduce over xGMI inside the hipGraph-captured decode step), global batch B (strong
+  scaling) - the latency-oriented deployment and the one a model too large for one GPU needs.
+
+Under a launcher each rank's bench.py process is only an orchestrator: every phase runs in a
+child process of its own (fresh HIP context, fresh rendezvous store, a time limit), so a phase
+that fails or hangs is reported in the JSON instead of taking the other phase's result with it.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -40,6 +50,8 @@ import torch
 
 from minivllm_amd.config import EngineConfig, model_preset
 from minivllm_amd.parallel.group import env_rank_world
+
+PHASE_PORT_OFFSET = {"dp": 101, "tp": 202}
 
 
 def make_config(args, model_name: str, world: int) -> EngineConfig:
@@ -69,15 +81,28 @@ class _ReplicaTimer:
         if what == "timer_start":
             self.t0 = time.perf_counter()
             return None
-        t = torch.tensor([time.perf_counter() - self.t0], dtype=torch.float64, device="cuda")
+        dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+        t = torch.tensor([time.perf_counter() - self.t0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
 
+class _LocalTimer:
+    """Single replica, no process group: drain the device around the timed region."""
+
+    def call(self, what: str):
+        torch.cuda.synchronize()
+        if what == "timer_start":
+            self.t0 = time.perf_counter()
+            return None
+        return time.perf_counter() - self.t0
+
+
 def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = False):
     """``replicas=False``: one tensor-parallel engine over all ranks (rank 0 drives).
-    ``replicas=True``: every rank runs its own single-GPU engine on the same workload
+    ``replicas=True``: every rank runs its own single-GPU engine on its own prompts
     (data parallel); the returned numbers are per replica."""
+    import torch.distributed as dist
     from minivllm_amd.engine.llm_engine import LLMEngine, run_worker
     from minivllm_amd.sampling_parameters import SamplingParams
     cfg = make_config(args, model_name, 1 if replicas else world)
@@ -87,8 +112,11 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
     t_init = time.perf_counter()
     eng = LLMEngine(cfg, spawn_workers=False)
     init_s = time.perf_counter() - t_init
-    runner = _ReplicaTimer() if replicas else eng.model_runner
-    rng = np.random.default_rng(0)
+    if replicas:
+        runner = _ReplicaTimer() if dist.is_initialized() else _LocalTimer()
+    else:
+        runner = eng.model_runner
+    rng = np.random.default_rng(rank if replicas else 0)     # every replica has its own prompts
     vocab = cfg.model.vocab_size
     W, K, S, B = args.warmup, args.steps, args.seq_len, args.batch
 
@@ -142,6 +170,84 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
     return res
 
 
+def _round(d):
+    return None if d is None else {k: (round(v, 3) if isinstance(v, float) else v)
+                                   for k, v in d.items()}
+
+
+# ------------------------------------------------------------------ phases (run in a child)
+def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
+    """Body of one phase.  Returns {'main': ..., 'second': ...} on rank 0, None elsewhere."""
+    torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    os.environ["MINIVLLM_KEEP_PG"] = "1"         # two engines in a row share one process group
+    models = [args.model] + ([args.second_model] if args.second_model
+                             and args.second_model != args.model else [])
+    if phase == "dp" and world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("MINIVLLM_DIST_BACKEND", "nccl")
+        kw = ({"device_id": torch.device("cuda", torch.cuda.current_device())}
+              if backend == "nccl" else {})
+        addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, init_method=f"tcp://{addr}:{os.environ['MASTER_PORT']}",
+                                rank=rank, world_size=world, **kw)
+    out = [bench_model(args, m, rank, world, replicas=(phase != "tp")) for m in models]
+    if rank != 0:
+        return None
+    return {"main": out[0], "second": out[1] if len(out) > 1 else None}
+
+
+def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int):
+    """Run ``phase`` in a child process of this rank (the children of all ranks form the job of
+    that phase).  Returns rank 0's result dict, or {'error': ...}."""
+    env = dict(os.environ)
+    for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
+        env.pop(k)                               # the child hosts its own rendezvous store
+    env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", args.port))
+                             + PHASE_PORT_OFFSET[phase])
+    env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
+               MINIVLLM_BENCH_PHASE=phase)
+    cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+    t0 = time.time()
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    stdout = None
+    while stdout is None:
+        try:
+            stdout, _ = proc.communicate(timeout=30)
+        except subprocess.TimeoutExpired:
+            waited = time.time() - t0
+            if waited > args.phase_timeout:
+                proc.kill()                      # exactly this rank's child, by pid
+                proc.communicate()
+                return {"error": f"{phase} phase exceeded {args.phase_timeout}s and was stopped"}
+            if rank == 0:
+                print(f"[bench] {phase} phase running for {waited:.0f}s", file=sys.stderr,
+                      flush=True)
+    if proc.returncode != 0:
+        return {"error": f"{phase} phase child exited with code {proc.returncode}"}
+    if rank != 0:
+        return None
+    for line in reversed(stdout.strip().splitlines()):
+        if line.startswith("{"):
+            res = json.loads(line)
+            res["phase_wall_s"] = round(time.time() - t0, 1)
+            return res
+    return {"error": f"{phase} phase printed no result"}
+
+
+def published_reference_check():
+    """The only numbers the reference publishes: SiluAndMul fp32 timings on one A6000."""
+    try:
+        from benchmark_activation import PUBLISHED_A6000_MS, time_layer
+        from minivllm_amd.layers.activation import SiluAndMul
+        shape = (4000, 8000)
+        ms = time_layer(SiluAndMul(), torch.randn(*shape, device="cuda", dtype=torch.float32))
+        return {"op": "SiluAndMul forward 4000x8000 fp32 (reference method)",
+                "ms": round(ms, 4), "reference_a6000_ms": PUBLISHED_A6000_MS[shape],
+                "speedup": round(PUBLISHED_A6000_MS[shape] / ms, 2)}
+    except Exception as e:                       # never lose the headline over the side check
+        return {"error": repr(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,7 +256,7 @@ def main():
     ap.add_argument("--model", default="qwen3-8b")
     ap.add_argument("--second-model", default="qwen3-0.6b",
                     help="also measured and reported under 'secondary' ('' to skip)")
-    ap.add_argument("--batch", type=int, default=256, help="decode batch (sequences)")
+    ap.add_argument("--batch", type=int, default=256, help="decode batch (sequences) per engine")
     ap.add_argument("--seq-len", type=int, default=1024, help="prompt / context length")
     ap.add_argument("--prefill-tokens", type=int, default=16384, help="tokens per prefill step")
     ap.add_argument("--block-size", type=int, default=256)
@@ -159,8 +265,10 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug)")
     ap.add_argument("--kv-blocks", type=int, default=None)
     ap.add_argument("--port", type=int, default=29533)
-    ap.add_argument("--no-dp", action="store_true",
-                    help="with N > 1, skip the extra data-parallel (N replicas) measurement")
+    ap.add_argument("--no-dp", action="store_true", help="with N > 1, skip the data-parallel phase")
+    ap.add_argument("--no-tp", action="store_true", help="with N > 1, skip the tensor-parallel phase")
+    ap.add_argument("--phase-timeout", type=int, default=600,
+                    help="time limit in seconds of one phase (N > 1)")
     args = ap.parse_args()
 
     if os.environ.get("MINIVLLM_HANG_DUMP"):     # debugging aid: dump all stacks if stuck
@@ -172,57 +280,93 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run "
                      "(one rank per GPU)")
         args.gpus = world
-    torch.cuda.set_device(local_rank % torch.cuda.device_count())
-    os.environ["MINIVLLM_KEEP_PG"] = "1"     # two engines in a row share one process group
 
-    main_res = bench_model(args, args.model, rank, world)
-    second = None
-    if args.second_model and args.second_model != args.model:
-        second = bench_model(args, args.second_model, rank, world)
-    dp = None
-    if world > 1 and not args.no_dp:
-        # same GPUs as N independent replicas (each serves its own batch of B sequences)
-        dp = bench_model(args, args.model, rank, world, replicas=True)
+    phase = os.environ.get("MINIVLLM_BENCH_PHASE")
+    if phase:                                    # child of an orchestrating rank
+        res = run_phase(args, phase, rank, local_rank, world)
+        if rank == 0:
+            if phase == "dp":
+                res["published_reference_check"] = published_reference_check()
+            print(json.dumps(res), flush=True)
+        return
+
+    B = args.batch
+    base = {"unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "higher_is_better": True, "vs_baseline": None, "dtype": "bf16",
+            "data": "synthetic random token prompts, random-init weights"}
+    cfg_common = {"model": args.model, "seq_len": args.seq_len,
+                  "prefill_tokens_per_step": args.prefill_tokens, "kv_block_size": args.block_size,
+                  "hipgraph_decode": not args.eager,
+                  **({"layers_override": args.layers} if args.layers else {})}
+    metric = f"decode tok/s ({args.model}, engine step); prefill tok/s in prefill_tok_s"
+
+    def headline(m):
+        return (round(m.get("decode_tok_s", m.get("prefill_tok_s")), 1),
+                round(m.get("decode_ms_per_step", m.get("prefill_ms_per_step")), 3))
+
+    if world == 1:
+        res = run_phase(args, "single", rank, local_rank, world)
+        m, second = res["main"], res["second"]
+        value, ms = headline(m)
+        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "weak",
+               "config": {**cfg_common, "global_batch": B, "parallelism": "tp1"}, **_round(m),
+               "published_reference_check": published_reference_check()}
+        if second is not None:
+            out["secondary"] = {"model": args.second_model, **_round(second)}
+        print(json.dumps(out), flush=True)
+        return
+
+    # ---- N > 1: orchestrate one child per phase --------------------------------------
+    dp = None if args.no_dp else spawn_phase(args, "dp", rank, local_rank, world)
+    tp = None if args.no_tp else spawn_phase(args, "tp", rank, local_rank, world)
     if rank != 0:
         return
-    published = None
-    try:
-        # the only numbers the reference publishes: SiluAndMul fp32 timings (1x A6000)
-        from benchmark_activation import PUBLISHED_A6000_MS, time_layer
-        from minivllm_amd.layers.activation import SiluAndMul
-        shape = (4000, 8000)
-        ms = time_layer(SiluAndMul(), torch.randn(*shape, device="cuda", dtype=torch.float32))
-        published = {"op": "SiluAndMul forward 4000x8000 fp32 (reference method)",
-                     "ms": round(ms, 4), "reference_a6000_ms": PUBLISHED_A6000_MS[shape],
-                     "speedup": round(PUBLISHED_A6000_MS[shape] / ms, 2)}
-    except Exception as e:                       # never lose the headline over the side check
-        published = {"error": repr(e)}
-    value = main_res.get("decode_tok_s", main_res.get("prefill_tok_s"))
-    ms = main_res.get("decode_ms_per_step", main_res.get("prefill_ms_per_step"))
-    out = {
-        "metric": f"decode tok/s ({args.model}, engine step); prefill tok/s in prefill_tok_s",
-        "value": round(value, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "bf16",
-        "data": "synthetic random token prompts, random-init weights",
-        "config": {"model": args.model, "global_batch": args.batch, "seq_len": args.seq_len,
-                   "parallelism": f"tp{world}", "prefill_tokens_per_step": args.prefill_tokens,
-                   "kv_block_size": args.block_size, "hipgraph_decode": not args.eager,
-                   **({"layers_override": args.layers} if args.layers else {})},
-        **{k: (round(v, 3) if isinstance(v, float) else v) for k, v in main_res.items()},
-    }
-    if dp is not None:
-        out["data_parallel_replicas"] = {
-            "parallelism": f"dp{world}", "scaling": "weak", "global_batch": args.batch * world,
-            "decode_tok_s": round(dp.get("decode_tok_s", 0.0) * world, 1),
-            "prefill_tok_s": round(dp.get("prefill_tok_s", 0.0) * world, 1),
-            "decode_ms_per_step": round(dp.get("decode_ms_per_step", 0.0), 3)}
-    out["published_reference_check"] = published
-    if second is not None:
-        out["secondary"] = {"model": args.second_model,
-                            **{k: (round(v, 3) if isinstance(v, float) else v)
-                               for k, v in second.items()}}
+
+    def ok(r):
+        return r is not None and "error" not in r and r.get("main")
+
+    def scaled(m):                               # per-replica numbers -> whole job
+        d = dict(m)
+        for k in ("decode_tok_s", "prefill_tok_s", "prefill_tokens_per_step"):
+            if k in d:
+                d[k] = d[k] * world
+        return d
+
+    def tp_section(r):
+        if not ok(r):
+            return r
+        sec = {"parallelism": f"tp{world}", "scaling": "strong", "global_batch": B,
+               **_round(r["main"]), "phase_wall_s": r.get("phase_wall_s")}
+        if r.get("second"):
+            sec["secondary"] = {"model": args.second_model, **_round(r["second"])}
+        return sec
+
+    if ok(dp):
+        m = scaled(dp["main"])
+        value, ms = headline(m)
+        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "weak",
+               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "replica": "tp1, one engine per GPU"},
+               **_round(m), "phase_wall_s": dp.get("phase_wall_s"),
+               "published_reference_check": dp.get("published_reference_check")}
+        if dp.get("second"):
+            out["secondary"] = {"model": args.second_model, **_round(scaled(dp["second"]))}
+        if tp is not None:
+            out["tensor_parallel"] = tp_section(tp)
+    elif ok(tp):
+        value, ms = headline(tp["main"])
+        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "strong",
+               "config": {**cfg_common, "global_batch": B, "parallelism": f"tp{world}"},
+               **_round(tp["main"]), "data_parallel_replicas": dp}
+        if tp.get("second"):
+            out["secondary"] = {"model": args.second_model, **_round(tp["second"])}
+    else:
+        out = {"metric": metric, "value": 0.0, **base, "ms_per_step": None, "scaling": "weak",
+               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}"},
+               "data_parallel_replicas": dp, "tensor_parallel": tp}
     print(json.dumps(out), flush=True)
+    if not (ok(dp) or ok(tp)):
+        sys.exit(1)
 
 
 if __name__ == "__main__":

@@ -128,6 +128,11 @@ class EngineConfig:
     log_stats: bool = False
     tuned_gemms: bool = True           # load the shipped TunableOp table for library GEMMs
     checkpoint_path: Optional[str] = None
+    # first GPU of this engine's tensor-parallel group when LOCAL_RANK is not set by a launcher
+    # (data-parallel replicas started from one process each take their own range of devices)
+    device_base: int = 0
+    # number of engine replicas behind engine.dp_engine.DataParallelEngine (1 = none)
+    data_parallel_size: int = 1
 
     # --- derived ---------------------------------------------------------
     def resolved_device(self) -> str:

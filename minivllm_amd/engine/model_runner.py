@@ -83,7 +83,8 @@ class ModelRunner:
         self.enforce_eager = cfg.enforce_eager
         dev_type = cfg.resolved_device()
         if dev_type == "cuda":
-            local = int(os.environ.get("LOCAL_RANK", rank)) if "LOCAL_RANK" in os.environ else rank
+            local = (int(os.environ["LOCAL_RANK"]) if "LOCAL_RANK" in os.environ
+                     else cfg.device_base + rank)
             self.device = torch.device("cuda", local % max(torch.cuda.device_count(), 1))
             torch.cuda.set_device(self.device)
         else:

@@ -21,9 +21,10 @@ _TP_RANK = 0
 _TP_SIZE = 1
 _TP_GROUP: Optional[dist.ProcessGroup] = None
 _OWNS_DEFAULT_GROUP = False
-# gloo moves GPU tensors through host memory on its own streams; when several ranks share one
-# device (single-GPU rehearsals of the TP path) queued kernels of one rank can starve the other
-# rank's copies, so the device is drained before every collective.  Never set with RCCL.
+# gloo has no device transport: with GPU tensors (several ranks sharing one device, used only to
+# rehearse the TP control flow on a single-GPU machine) every collective is staged through host
+# memory HERE - copy to the host, CPU collective, copy back - instead of by gloo's own
+# device-tensor path, which can deadlock when two processes share one GPU.  Never set with RCCL.
 _HOST_STAGED = False
 
 
@@ -45,11 +46,6 @@ def is_initialized() -> bool:
 
 def host_staged_collectives() -> bool:
     return _HOST_STAGED
-
-
-def _drain(x: torch.Tensor) -> None:
-    if _HOST_STAGED and x.is_cuda:
-        torch.cuda.synchronize()
 
 
 def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
@@ -106,18 +102,26 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over the TP group; returns ``x`` (the reference returns the
     collective's return value instead of the tensor: layers/linear.py:218-219)."""
     if _TP_GROUP is not None:
-        _drain(x)
-        dist.all_reduce(x, group=_TP_GROUP)
+        if _HOST_STAGED and x.is_cuda:
+            h = x.cpu()
+            dist.all_reduce(h, group=_TP_GROUP)
+            x.copy_(h)
+        else:
+            dist.all_reduce(x, group=_TP_GROUP)
     return x
+
+
+def _all_gather_parts(x: torch.Tensor) -> List[torch.Tensor]:
+    src = x.cpu() if (_HOST_STAGED and x.is_cuda) else x.contiguous()
+    parts: List[torch.Tensor] = [torch.empty_like(src) for _ in range(_TP_SIZE)]
+    dist.all_gather(parts, src, group=_TP_GROUP)
+    return [p.to(x.device) for p in parts] if src.device != x.device else parts
 
 
 def tp_all_gather(x: torch.Tensor, dim: int = -1) -> torch.Tensor:
     if _TP_GROUP is None:
         return x
-    parts: List[torch.Tensor] = [torch.empty_like(x) for _ in range(_TP_SIZE)]
-    _drain(x)
-    dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)
-    return torch.cat(parts, dim=dim)
+    return torch.cat(_all_gather_parts(x), dim=dim)
 
 
 def tp_all_gather_stack(x: torch.Tensor) -> torch.Tensor:
@@ -129,10 +133,7 @@ def tp_all_gather_stack(x: torch.Tensor) -> torch.Tensor:
         out = torch.empty((_TP_SIZE,) + tuple(x.shape), dtype=x.dtype, device=x.device)
         dist.all_gather_into_tensor(out, x.contiguous(), group=_TP_GROUP)
         return out
-    parts: List[torch.Tensor] = [torch.empty_like(x) for _ in range(_TP_SIZE)]
-    _drain(x)
-    dist.all_gather(parts, x.contiguous(), group=_TP_GROUP)
-    return torch.stack(parts)
+    return torch.stack(_all_gather_parts(x))
 
 
 def tp_gather(x: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Tensor]:
@@ -140,11 +141,10 @@ def tp_gather(x: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Te
     layers/embedding_head.py:67-75)."""
     if _TP_GROUP is None:
         return x
-    x = x.contiguous()
-    parts = [torch.empty_like(x) for _ in range(_TP_SIZE)] if _TP_RANK == dst else None
-    _drain(x)
-    dist.gather(x, parts, dst=dst, group=_TP_GROUP)
-    return torch.cat(parts, dim=dim) if parts is not None else None
+    src = x.cpu() if (_HOST_STAGED and x.is_cuda) else x.contiguous()
+    parts = [torch.empty_like(src) for _ in range(_TP_SIZE)] if _TP_RANK == dst else None
+    dist.gather(src, parts, dst=dst, group=_TP_GROUP)
+    return torch.cat(parts, dim=dim).to(x.device) if parts is not None else None
 
 
 def tp_barrier() -> None:
