@@ -131,6 +131,9 @@ class EngineConfig:
     # first GPU of this engine's tensor-parallel group when LOCAL_RANK is not set by a launcher
     # (data-parallel replicas started from one process each take their own range of devices)
     device_base: int = 0
+    # testing aid: with world_size 1 still create a (single-rank) process group and run every
+    # tensor-parallel collective through it, graph capture included
+    force_tp_group: bool = False
     # number of engine replicas behind engine.dp_engine.DataParallelEngine (1 = none)
     data_parallel_size: int = 1
 

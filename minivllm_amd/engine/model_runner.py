@@ -94,7 +94,7 @@ class ModelRunner:
                                                     else torch.float32)
 
         pg.init_tensor_parallel(rank, cfg.world_size, cfg.dist_backend, cfg.master_addr,
-                                cfg.master_port, self.device)
+                                cfg.master_port, self.device, force_group=cfg.force_tp_group)
 
         if self.on_gpu and cfg.tuned_gemms:
             from minivllm_amd.utils.gemm_tuning import enable_tuned_gemms
@@ -534,7 +534,7 @@ class ModelRunner:
             vals, idx = hip.sample_local(logits, temperatures, self.cfg.seed, step,
                                          vocab_offset=head.vocab_start,
                                          valid_vocab=head.num_embeddings)
-            if self.world_size == 1:
+            if self.world_size == 1 and not pg.collectives_active():
                 return idx
             pair = torch.stack([vals, idx.to(torch.float32)], dim=-1)          # [B, 2]
             allp = pg.tp_all_gather_stack(pair)                                 # [tp, B, 2]

@@ -50,7 +50,7 @@ class VocabParallelEmbedding(nn.Module):
             param.data[:rows].copy_(loaded_weight.narrow(0, self.vocab_start, rows))
 
     def forward(self, input_ids: torch.Tensor) -> torch.Tensor:
-        if self.tp_size == 1:
+        if self.tp_size == 1 and not pg.collectives_active():
             return F.embedding(input_ids, self.weight)
         mask = (input_ids >= self.vocab_start) & (input_ids < self.vocab_end)
         local = (input_ids - self.vocab_start) * mask
@@ -72,7 +72,7 @@ class ParallelLMHead(VocabParallelEmbedding):
 
     def forward(self, hidden: torch.Tensor) -> Optional[torch.Tensor]:
         logits = self.local_logits(hidden)
-        if self.tp_size > 1:
+        if self.tp_size > 1 or pg.collectives_active():
             logits = pg.tp_gather(logits, dst=0, dim=-1)
             if logits is None:
                 return None

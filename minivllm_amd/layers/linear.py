@@ -152,7 +152,7 @@ class RowParallelLinear(LinearBase):
 
     def forward(self, x):
         bias = self.bias if self.tp_rank == 0 else None
-        if self.tp_size > 1 and self.reduce_results:
+        if (self.tp_size > 1 or pg.collectives_active()) and self.reduce_results:
             from minivllm_amd.parallel.overlap import row_parallel_linear
             return row_parallel_linear(x, self.weight, bias)
         return ops.linear(x, self.weight, bias)

@@ -44,6 +44,12 @@ def is_initialized() -> bool:
     return _TP_SIZE > 1 and _TP_GROUP is not None
 
 
+def collectives_active() -> bool:
+    """True when the sharded code path (collectives included) must run: more than one rank, or
+    a forced single-rank group."""
+    return _TP_GROUP is not None
+
+
 def host_staged_collectives() -> bool:
     return _HOST_STAGED
 
@@ -51,11 +57,13 @@ def host_staged_collectives() -> bool:
 def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
                          master_addr: str = "127.0.0.1", master_port: int = 29512,
                          device: Optional[torch.device] = None,
-                         timeout_s: float = 600.0) -> None:
-    """Join the TP group.  Reuses an already initialised default group (torchrun)."""
+                         timeout_s: float = 600.0, force_group: bool = False) -> None:
+    """Join the TP group.  Reuses an already initialised default group (torchrun).
+    ``force_group`` creates the group even for one rank, so that every collective of the
+    sharded code path really runs (and is captured into the decode graphs) on a single GPU."""
     global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP, _HOST_STAGED
     _TP_RANK, _TP_SIZE = rank, world_size
-    if world_size == 1:
+    if world_size == 1 and not force_group:
         _TP_GROUP = None
         return
     on_gpu = device is not None and torch.device(device).type == "cuda"

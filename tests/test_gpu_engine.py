@@ -116,14 +116,11 @@ def test_sampling_temperature_runs(gpu):
     e.exit()
 
 
-@pytest.mark.skipif(__import__("os").environ.get("MINIVLLM_SHARED_GPU_TP") != "1",
-                    reason="rehearsal of the TP path with two ranks on ONE GPU over gloo; gloo's "
-                           "host-staged GPU collectives stall now and then when ranks share a "
-                           "device, so it only runs on request (MINIVLLM_SHARED_GPU_TP=1)")
 def test_tp2_on_one_gpu_matches_tp1(gpu):
-    """Both TP ranks share cuda:0 and talk through gloo (RCCL refuses two ranks on one
-    device): exercises the sharded HIP path, the shard-wise sampler + (value, index)
-    exchange, and the control channel.  Eager only: gloo collectives are not capturable."""
+    """Both TP ranks share cuda:0 and talk through gloo, staged through host memory by
+    parallel/group.py (RCCL refuses two ranks on one device): exercises the sharded HIP path,
+    the shard-wise sampler + (value, index) exchange, and the control channel.  Eager only:
+    host-staged collectives are not capturable."""
     import os
     from minivllm_amd.engine.llm_engine import LLMEngine
     prompts = _prompts(5, seed=4)
@@ -139,3 +136,26 @@ def test_tp2_on_one_gpu_matches_tp1(gpu):
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
     assert same / total > 0.9, (same, total)
+
+
+def test_rccl_collectives_inside_decode_graphs(gpu):
+    """A forced single-rank RCCL group makes the engine take the sharded code path on one GPU:
+    embedding / row-parallel all-reduce and the sampler's (value, index) all-gather run through
+    RCCL and are captured into the decode hipGraphs.  Tokens must equal the plain engine's
+    (sampling noise is keyed by global vocabulary index, so the split is invisible)."""
+    import os
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    from minivllm_amd.parallel import group as pg
+    prompts = _prompts(6, seed=7)
+    sp = SamplingParams(temperature=0.7, max_tokens=20, ignore_eos=True)
+    plain = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[2, 8]))
+    want = plain.generate(prompts, sp)["token_ids"]
+    plain.exit()
+    forced = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[2, 8], force_tp_group=True,
+                            dist_backend="nccl", master_port=29850 + os.getpid() % 100))
+    assert pg.collectives_active() and not pg.host_staged_collectives()
+    assert set(forced.model_runner.graphs) == {2, 8}
+    got = forced.generate(prompts, sp)["token_ids"]
+    forced.exit()
+    assert not pg.collectives_active()
+    assert got == want

@@ -144,6 +144,21 @@ def test_tp2_gloo_matches_tp1():
     assert not pg.is_initialized()                  # exit() tore the group down
 
 
+def test_forced_single_rank_group_runs_the_sharded_path():
+    """world_size 1 with force_tp_group: collectives go through a real (gloo) group."""
+    import dataclasses
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    port = 29300 + os.getpid() % 300
+    single, _ = _generate(1, port)
+    eng = LLMEngine(dataclasses.replace(_cfg(1, port + 2), force_tp_group=True))
+    assert pg.collectives_active()
+    rng = np.random.default_rng(3)
+    prompts = [rng.integers(0, 331, size=n).tolist() for n in (5, 21, 9, 16, 30)]
+    out = eng.generate(prompts, SamplingParams(temperature=0, max_tokens=10, ignore_eos=True))
+    eng.exit()
+    assert out["token_ids"] == single and not pg.collectives_active()
+
+
 # ------------------------------------------- chunk-pipelined row-parallel GEMM
 def _overlap_worker(rank, world, port, q):
     import torch.distributed as dist
