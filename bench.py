@@ -27,6 +27,8 @@ With N > 1 two deployments of the same N GPUs are measured:
 * tensor parallel (``tensor_parallel`` in the JSON): ONE engine sharded over the N GPUs (RCCL
   all-reduce over xGMI inside the hipGraph-captured decode step), global batch B (strong
   scaling) - the latency-oriented deployment and the one a model too large for one GPU needs.
+  ``tensor_parallel_p2p_allreduce`` repeats it with decode-sized all-reduces done by the
+  peer-to-peer kernel of ``parallel/custom_allreduce.py`` instead of RCCL.
 
 Under a launcher each rank's bench.py process is only an orchestrator: every phase runs in a
 child process of its own (fresh HIP context, fresh rendezvous store, a time limit), so a phase
@@ -51,7 +53,7 @@ import torch
 from minivllm_amd.config import EngineConfig, model_preset
 from minivllm_amd.parallel.group import env_rank_world
 
-PHASE_PORT_OFFSET = {"dp": 101, "tp": 202}
+PHASE_PORT_OFFSET = {"dp": 101, "tp": 202, "tpc": 303}
 
 
 def make_config(args, model_name: str, world: int) -> EngineConfig:
@@ -181,7 +183,7 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ["MINIVLLM_KEEP_PG"] = "1"         # two engines in a row share one process group
     models = [args.model] + ([args.second_model] if args.second_model
-                             and args.second_model != args.model else [])
+                             and args.second_model != args.model and phase != "tpc" else [])
     if phase == "dp" and world > 1:
         import torch.distributed as dist
         backend = os.environ.get("MINIVLLM_DIST_BACKEND", "nccl")
@@ -190,7 +192,8 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, init_method=f"tcp://{addr}:{os.environ['MASTER_PORT']}",
                                 rank=rank, world_size=world, **kw)
-    out = [bench_model(args, m, rank, world, replicas=(phase != "tp")) for m in models]
+    out = [bench_model(args, m, rank, world, replicas=(phase not in ("tp", "tpc")))
+           for m in models]
     if rank != 0:
         return None
     return {"main": out[0], "second": out[1] if len(out) > 1 else None}
@@ -206,6 +209,8 @@ def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int):
                              + PHASE_PORT_OFFSET[phase])
     env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
                MINIVLLM_BENCH_PHASE=phase)
+    if phase == "tpc":                           # TP again, all-reduce by the peer-to-peer kernel
+        env["MINIVLLM_CUSTOM_AR"] = "1"
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     t0 = time.time()
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
@@ -267,6 +272,8 @@ def main():
     ap.add_argument("--port", type=int, default=29533)
     ap.add_argument("--no-dp", action="store_true", help="with N > 1, skip the data-parallel phase")
     ap.add_argument("--no-tp", action="store_true", help="with N > 1, skip the tensor-parallel phase")
+    ap.add_argument("--no-p2p", action="store_true",
+                    help="with N > 1, skip the TP phase that uses the peer-to-peer all-reduce kernel")
     ap.add_argument("--phase-timeout", type=int, default=600,
                     help="time limit in seconds of one phase (N > 1)")
     args = ap.parse_args()
@@ -319,6 +326,8 @@ def main():
     # ---- N > 1: orchestrate one child per phase --------------------------------------
     dp = None if args.no_dp else spawn_phase(args, "dp", rank, local_rank, world)
     tp = None if args.no_tp else spawn_phase(args, "tp", rank, local_rank, world)
+    tpc = (None if args.no_tp or args.no_p2p or world not in (2, 4, 8)
+           else spawn_phase(args, "tpc", rank, local_rank, world))
     if rank != 0:
         return
 
@@ -353,6 +362,8 @@ def main():
             out["secondary"] = {"model": args.second_model, **_round(scaled(dp["second"]))}
         if tp is not None:
             out["tensor_parallel"] = tp_section(tp)
+        if tpc is not None:
+            out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
     elif ok(tp):
         value, ms = headline(tp["main"])
         out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "strong",

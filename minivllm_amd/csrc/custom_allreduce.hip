@@ -1,0 +1,221 @@
+// All-reduce (sum) for decode-sized tensors over peer-mapped memory: every rank reads the other
+// ranks' buffers directly over xGMI instead of going through a ring.
+//
+// The 8 GPUs of a node are fully connected by point-to-point xGMI links, so a rank can pull from
+// all 7 peers at once, one link each.  For the messages of a decode step ([B, hidden] bf16, tens
+// of KB to a few MB) a ring collective is latency-bound (2 (P - 1) dependent hops); here the
+// whole operation is ONE kernel per rank with three flag barriers:
+//
+//   one-shot (small):  copy x -> my staging buffer | barrier | x = sum over ranks of staging
+//   two-shot:          copy | barrier | reduce MY 1/P slice from all ranks' staging into my
+//                      result buffer | barrier | gather the P reduced slices | barrier
+//
+// Two-shot moves 2 (P-1)/P of the message over each rank's links (like reduce-scatter +
+// all-gather), one-shot (P-1) times the message but with one barrier less.
+//
+// Memory model.  Staging / result buffers and the flag words live in hipMalloc'd memory that the
+// peers map through IPC handles.  Data written inside the kernel is published with a
+// system-scope release (write back L2) after every storing wave has drained its stores; flags
+// are system-scope relaxed atomics written to the PEER's flag array and polled locally; the
+// consumer runs a system-scope acquire (invalidate) after its poll matched and before the first
+// load of peer data.  Block b of every rank copies and reads the same element subset, so a
+// block only ever depends on block b of its peers and needs no grid-wide barrier.  Every spin is
+// bounded: on expiry the kernel sets a status word and returns, it never hangs the device.
+#include "common.h"
+#include <string.h>
+
+using namespace mvl;
+
+namespace {
+
+constexpr int kMaxRanks = 8;
+constexpr int kMaxBlocks = 64;
+constexpr int kThreads = 512;
+constexpr long kSpinLimit = 1L << 27;          // ~ seconds of polling, then give up
+
+// One per rank, in peer-visible memory.  counter[phase][block][src rank] is written by rank
+// `src`; epoch[block] is this rank's own call count (one more per launch).
+struct Flags {
+    uint32_t counter[3][kMaxBlocks][kMaxRanks];
+    uint32_t epoch[kMaxBlocks];
+    uint32_t status;                           // != 0: a spin expired (sticky)
+};
+
+struct Peers {
+    Flags* flags[kMaxRanks];
+    uint16_t* stage[kMaxRanks];                // inputs, one buffer per rank
+    uint16_t* result[kMaxRanks];               // reduced slices (two-shot)
+};
+
+// All data stores of the block are done -> tell every peer's block `b`, then wait for theirs.
+template <int P>
+__device__ __forceinline__ void block_barrier(const Peers& pr, int rank, int phase, uint32_t epoch,
+                                              bool publish) {
+    if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains
+    __syncthreads();
+    Flags* mine = pr.flags[rank];
+    if (threadIdx.x < P) {
+        if (publish) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope: write back
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __hip_atomic_store(&pr.flags[threadIdx.x]->counter[phase][blockIdx.x][rank], epoch,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        long spins = 0;
+        while (__hip_atomic_load(&mine->counter[phase][blockIdx.x][threadIdx.x], __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            if (++spins > kSpinLimit) {
+                __hip_atomic_store(&mine->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                 // system scope: invalidate
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+}
+
+template <int CODE>
+__device__ __forceinline__ void accumulate(float (&acc)[8], u32x4_t v) {
+    float f[8];
+    unpack8<CODE>(v, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += f[j];
+}
+
+// n_vec = number of 16-byte vectors of the message.  TWO_SHOT needs n_vec % P == 0.
+template <int CODE, int P, bool TWO_SHOT>
+__global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank,
+                                                               uint16_t* __restrict__ x, long n_vec) {
+    Flags* mine = pr.flags[rank];
+    const uint32_t epoch = mine->epoch[blockIdx.x] + 1;     // same on every rank: one per call
+    const long stride = (long)gridDim.x * kThreads;
+    const long first = (long)blockIdx.x * kThreads + threadIdx.x;
+    u32x4_t* xv = reinterpret_cast<u32x4_t*>(x);
+
+    if (!TWO_SHOT) {
+        u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
+        for (long i = first; i < n_vec; i += stride) st[i] = xv[i];
+        block_barrier<P>(pr, rank, 0, epoch, true);
+        for (long i = first; i < n_vec; i += stride) {
+            u32x4_t v[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                v[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[i];
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < P; ++p) accumulate<CODE>(acc, v[p]);  // rank order: same bits everywhere
+            xv[i] = pack8<CODE>(acc);
+        }
+        block_barrier<P>(pr, rank, 2, epoch, false);        // peers are done reading my staging
+    } else {
+        const long part = n_vec / P;                         // vectors per slice
+        u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
+        // block b moves the same relative subset of EVERY slice, on every rank
+        for (int s = 0; s < P; ++s)
+            for (long i = first; i < part; i += stride) st[s * part + i] = xv[s * part + i];
+        block_barrier<P>(pr, rank, 0, epoch, true);
+        u32x4_t* res = reinterpret_cast<u32x4_t*>(pr.result[rank]);
+        for (long i = first; i < part; i += stride) {
+            u32x4_t v[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                v[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[rank * part + i];
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < P; ++p) accumulate<CODE>(acc, v[p]);
+            const u32x4_t o = pack8<CODE>(acc);
+            res[rank * part + i] = o;
+            xv[rank * part + i] = o;
+        }
+        block_barrier<P>(pr, rank, 1, epoch, true);
+        for (long i = first; i < part; i += stride) {
+            u32x4_t v[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                v[p] = reinterpret_cast<const u32x4_t*>(pr.result[p])[p * part + i];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (p != rank) xv[p * part + i] = v[p];
+        }
+        block_barrier<P>(pr, rank, 2, epoch, false);        // peers are done reading my buffers
+    }
+    if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+}
+
+template <int CODE, int P>
+int launch(const Peers& pr, int rank, void* x, long n_vec, bool two_shot, hipStream_t st) {
+    const long per_block = two_shot ? n_vec / P : n_vec;
+    long blocks = (per_block + kThreads - 1) / kThreads;
+    if (blocks < 1) blocks = 1;
+    if (blocks > kMaxBlocks) blocks = kMaxBlocks;
+    if (two_shot)
+        all_reduce_kernel<CODE, P, true><<<(unsigned)blocks, kThreads, 0, st>>>(pr, rank, (uint16_t*)x, n_vec);
+    else
+        all_reduce_kernel<CODE, P, false><<<(unsigned)blocks, kThreads, 0, st>>>(pr, rank, (uint16_t*)x, n_vec);
+    return MVL_CHECK_LAUNCH();
+}
+
+template <int CODE>
+int launch_p(const Peers& pr, int world, int rank, void* x, long n_vec, bool two_shot, hipStream_t st) {
+    switch (world) {
+        case 2: return launch<CODE, 2>(pr, rank, x, n_vec, two_shot, st);
+        case 4: return launch<CODE, 4>(pr, rank, x, n_vec, two_shot, st);
+        case 8: return launch<CODE, 8>(pr, rank, x, n_vec, two_shot, st);
+        default: return -1;
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ memory + IPC plumbing
+extern "C" size_t mvl_car_flags_bytes() { return sizeof(Flags); }
+extern "C" int mvl_car_ipc_handle_bytes() { return (int)sizeof(hipIpcMemHandle_t); }
+
+// Zero-initialised device allocation outside PyTorch's caching allocator (an IPC handle names a
+// whole allocation).  uncached != 0: fine-grained memory for the flag words.
+extern "C" int mvl_car_alloc(void** out, size_t bytes, int uncached) {
+    hipError_t e = uncached ? hipExtMallocWithFlags(out, bytes, hipDeviceMallocUncached)
+                            : hipMalloc(out, bytes);
+    if (e != hipSuccess) return (int)e;
+    return (int)hipMemset(*out, 0, bytes);
+}
+extern "C" int mvl_car_free(void* p) { return (int)hipFree(p); }
+extern "C" int mvl_car_ipc_get(void* p, void* handle_out) {
+    return (int)hipIpcGetMemHandle((hipIpcMemHandle_t*)handle_out, p);
+}
+extern "C" int mvl_car_ipc_open(const void* handle, void** out) {
+    hipIpcMemHandle_t h;
+    memcpy(&h, handle, sizeof(h));
+    return (int)hipIpcOpenMemHandle(out, h, hipIpcMemLazyEnablePeerAccess);
+}
+extern "C" int mvl_car_ipc_close(void* p) { return (int)hipIpcCloseMemHandle(p); }
+
+// flags / stage / result: `world` device pointers each, indexed by rank (own entries are the
+// local allocations, the others IPC mappings).  x: [n_elems] 16-bit elements, in place.
+extern "C" int mvl_car_all_reduce(void* const* flags, void* const* stage, void* const* result,
+                                  int world, int rank, void* x, long n_elems, int two_shot,
+                                  int dtype, void* stream) {
+    if (n_elems == 0) return 0;
+    if (world > kMaxRanks || n_elems % 8 != 0 || ((uintptr_t)x & 15) != 0) return -1;
+    const long n_vec = n_elems / 8;
+    if (two_shot && n_vec % world != 0) return -1;
+    Peers pr;
+    for (int p = 0; p < world; ++p) {
+        pr.flags[p] = (Flags*)flags[p];
+        pr.stage[p] = (uint16_t*)stage[p];
+        pr.result[p] = (uint16_t*)result[p];
+    }
+    auto st = (hipStream_t)stream;
+    return dtype == 0 ? launch_p<0>(pr, world, rank, x, n_vec, two_shot != 0, st)
+                      : launch_p<1>(pr, world, rank, x, n_vec, two_shot != 0, st);
+}
+
+// Reads the sticky status word (0 = every barrier of every call so far completed).
+extern "C" int mvl_car_status(const void* flags_self) {
+    uint32_t s = 0;
+    if (hipMemcpy(&s, &((const Flags*)flags_self)->status, sizeof(s), hipMemcpyDeviceToHost) != hipSuccess)
+        return -1;
+    return (int)s;
+}

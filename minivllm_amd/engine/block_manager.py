@@ -181,3 +181,150 @@ class BlockManager:
             "prefix_hit_rate": (self.num_prefix_hits / self.num_prefix_queries
                                 if self.num_prefix_queries else 0.0),
         }
+
+
+# ------------------------------------------------------------------ native implementation
+_HOST_LIB = None
+
+
+def _host_lib():
+    """``_host_core.so`` (csrc/host/block_manager.cpp, built by minivllm_amd.build), or None."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        import ctypes
+        import os
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                            "_host_core.so")
+        if not os.path.exists(path):
+            _HOST_LIB = False
+            return None
+        lib = ctypes.CDLL(path)
+        vp, i32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)
+        lib.mvl_bm_create.restype = vp
+        lib.mvl_bm_create.argtypes = [ctypes.c_int, ctypes.c_int]
+        lib.mvl_bm_destroy.argtypes = [vp]
+        lib.mvl_bm_num_free.argtypes = [vp]
+        lib.mvl_bm_allocate.restype = ctypes.c_long
+        lib.mvl_bm_allocate.argtypes = [vp, vp, ctypes.c_long, vp]
+        lib.mvl_bm_deallocate.argtypes = [vp, vp, ctypes.c_int]
+        lib.mvl_bm_append.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, vp]
+        lib.mvl_bm_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_long)]
+        lib.mvl_bm_ref_count.argtypes = [vp, ctypes.c_int]
+        lib.mvl_chain_hash.restype = ctypes.c_uint64
+        lib.mvl_chain_hash.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_uint64]
+        _HOST_LIB = lib
+    return _HOST_LIB or None
+
+
+class NativeBlockManager:
+    """Same interface and the same allocation decisions as :class:`BlockManager`, with the block
+    table bookkeeping, the free list and the xxh64 chain hashing in C++
+    (``csrc/host/block_manager.cpp``).  Sequences stay Python objects; their token ids cross the
+    boundary as int32 arrays only when a prompt is admitted or a block fills up."""
+
+    def __init__(self, num_blocks: int, block_size: int):
+        if num_blocks <= 0:
+            raise ValueError("num_blocks must be positive")
+        lib = _host_lib()
+        if lib is None:
+            raise RuntimeError("_host_core.so is missing: run `python -m minivllm_amd.build`")
+        self._lib = lib
+        self.block_size = block_size
+        self._n = num_blocks
+        self._h = lib.mvl_bm_create(num_blocks, block_size)
+        self._stats = (__import__("ctypes").c_long * 6)()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            self._lib.mvl_bm_destroy(h)
+
+    @staticmethod
+    def compute_hash(token_ids: List[int], prefix_hash: int = -1) -> int:
+        t = np.ascontiguousarray(token_ids, dtype=np.int32)
+        return int(_host_lib().mvl_chain_hash(t.ctypes.data, len(t), int(prefix_hash != -1),
+                                              0 if prefix_hash == -1 else prefix_hash))
+
+    @property
+    def num_free_blocks(self) -> int:
+        return self._lib.mvl_bm_num_free(self._h)
+
+    @property
+    def num_blocks(self) -> int:
+        return self._n
+
+    def ref_count(self, block_id: int) -> int:
+        return self._lib.mvl_bm_ref_count(self._h, block_id)
+
+    @property
+    def blocks(self) -> List[Block]:
+        """Snapshot for inspection (ids and reference counts; hashes and tokens stay native)."""
+        out = []
+        for i in range(self._n):
+            b = Block(i)
+            b.ref_count = self.ref_count(i)
+            out.append(b)
+        return out
+
+    def can_allocate(self, seq: Sequence) -> bool:
+        return self.num_free_blocks >= seq.num_blocks
+
+    def allocate(self, seq: Sequence) -> None:
+        assert not seq.block_table, "sequence already has blocks"
+        toks = np.ascontiguousarray(seq.token_ids, dtype=np.int32)
+        table = np.empty(seq.num_blocks, dtype=np.int32)
+        cached = self._lib.mvl_bm_allocate(self._h, toks.ctypes.data, len(toks), table.ctypes.data)
+        if cached < 0:
+            raise RuntimeError("allocate() without enough free blocks (check can_allocate first)")
+        seq.block_table = table.tolist()
+        seq.num_cached_tokens = int(cached)
+
+    def deallocate(self, seq: Sequence) -> None:
+        if seq.block_table:
+            table = np.asarray(seq.block_table, dtype=np.int32)
+            self._lib.mvl_bm_deallocate(self._h, table.ctypes.data, len(table))
+        seq.block_table = []
+        seq.num_cached_tokens = 0
+
+    def can_append(self, seq: Sequence) -> bool:
+        need_new = len(seq.block_table) < seq.num_blocks
+        return self.num_free_blocks >= int(need_new)
+
+    def append(self, seq: Sequence) -> None:
+        n = seq.num_tokens
+        bt = seq.block_table
+        last_tokens = None
+        if n % self.block_size == 0:                      # this step fills the last block
+            last_tokens = np.ascontiguousarray(seq.block(seq.num_blocks - 1), dtype=np.int32)
+        added = self._lib.mvl_bm_append(
+            self._h, len(bt), bt[-1] if bt else -1, bt[-2] if len(bt) > 1 else -1, n,
+            last_tokens.ctypes.data if last_tokens is not None else None)
+        if added == -2:
+            raise RuntimeError("append() without a free block (check can_append first)")
+        if added >= 0:
+            bt.append(added)
+        assert len(bt) == seq.num_blocks
+
+    @property
+    def num_prefix_hits(self) -> int:
+        return self.stats()["prefix_hits"]
+
+    @property
+    def num_prefix_queries(self) -> int:
+        return self.stats()["prefix_queries"]
+
+    def stats(self) -> dict:
+        self._lib.mvl_bm_stats(self._h, self._stats)
+        n, free, used, hashes, hits, queries = list(self._stats)
+        return {"num_blocks": n, "free": free, "used": used, "cached_hashes": hashes,
+                "prefix_hits": hits, "prefix_queries": queries,
+                "prefix_hit_rate": hits / queries if queries else 0.0}
+
+
+def make_block_manager(num_blocks: int, block_size: int, native: Optional[bool] = None):
+    """The C++ allocator when its library is built (default), else the Python one.
+    ``MINIVLLM_PY_HOST=1`` forces the Python implementation."""
+    import os
+    if native is None:
+        native = os.environ.get("MINIVLLM_PY_HOST") != "1" and _host_lib() is not None
+    return NativeBlockManager(num_blocks, block_size) if native else BlockManager(num_blocks, block_size)

@@ -96,6 +96,9 @@ class ModelRunner:
         pg.init_tensor_parallel(rank, cfg.world_size, cfg.dist_backend, cfg.master_addr,
                                 cfg.master_port, self.device, force_group=cfg.force_tp_group)
 
+        if (self.on_gpu and cfg.world_size > 1
+                and (cfg.custom_all_reduce or os.environ.get("MINIVLLM_CUSTOM_AR") == "1")):
+            pg.enable_custom_all_reduce(self.device)
         if self.on_gpu and cfg.tuned_gemms:
             from minivllm_amd.utils.gemm_tuning import enable_tuned_gemms
             enable_tuned_gemms()

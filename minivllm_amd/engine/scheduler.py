@@ -15,7 +15,7 @@ from __future__ import annotations
 from collections import deque
 from typing import Deque, List, Optional, Tuple
 
-from .block_manager import BlockManager
+from .block_manager import BlockManager, make_block_manager  # noqa: F401
 from .sequence import Sequence, SequenceStatus
 
 
@@ -23,7 +23,7 @@ class Scheduler:
     def __init__(self, max_num_sequences: int, max_num_batched_tokens: int,
                  max_cached_blocks: int, block_size: int, eos: int,
                  max_model_length: Optional[int] = None):
-        self.block_manager = BlockManager(max_cached_blocks, block_size)
+        self.block_manager = make_block_manager(max_cached_blocks, block_size)
         self.max_num_sequences = max_num_sequences
         self.max_num_batched_tokens = max_num_batched_tokens
         self.max_model_length = max_model_length

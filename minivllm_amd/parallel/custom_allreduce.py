@@ -1,0 +1,120 @@
+"""Peer-to-peer all-reduce for decode-sized tensors (``csrc/custom_allreduce.hip``).
+
+The reference all-reduces every row-parallel output with NCCL on the compute stream
+(reference: src/myvllm/layers/linear.py:216-221).  RCCL's ring needs 2 (P - 1) dependent hops,
+which for the [B, hidden] messages of a decode step (tens of KB to a few MB, 2 per layer) is pure
+latency.  The 8 GPUs of an MI355X node are fully connected by point-to-point xGMI links, so each
+rank can instead read all peers' buffers at once: one kernel per rank, one- or two-shot.
+
+Set-up (once per engine): every rank allocates a flag block, a staging buffer and a result buffer
+outside the PyTorch caching allocator, publishes their IPC handles through the process group and
+maps the peers' allocations.  ``all_reduce(x)`` then launches the kernel on the current stream;
+the call is hipGraph-capturable (pointers are fixed, the call counter lives in device memory).
+Messages that do not fit (too large, odd sizes, fp32) go to RCCL.
+
+Opt-in: ``EngineConfig.custom_all_reduce`` / ``MINIVLLM_CUSTOM_AR=1``.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+ONE_SHOT_MAX_BYTES = 256 << 10          # above this the two-shot form moves fewer bytes per link
+DEFAULT_MAX_BYTES = 8 << 20             # [1024, 4096] bf16
+
+
+class CustomAllReduce:
+    def __init__(self, group, rank: int, world_size: int, device: torch.device,
+                 max_bytes: int = DEFAULT_MAX_BYTES):
+        from minivllm_amd.ops import hip
+        if world_size not in (2, 4, 8):
+            raise ValueError("custom all-reduce supports 2, 4 or 8 ranks")
+        self._lib = lib = hip._lib
+        self.group, self.rank, self.world, self.device = group, rank, world_size, device
+        self.max_bytes = max_bytes
+        vp, sz = ctypes.c_void_p, ctypes.c_size_t
+        lib.mvl_car_flags_bytes.restype = sz
+        lib.mvl_car_alloc.argtypes = [ctypes.POINTER(vp), sz, ctypes.c_int]
+        lib.mvl_car_free.argtypes = [vp]
+        lib.mvl_car_ipc_get.argtypes = [vp, ctypes.c_char_p]
+        lib.mvl_car_ipc_open.argtypes = [ctypes.c_char_p, ctypes.POINTER(vp)]
+        lib.mvl_car_ipc_close.argtypes = [vp]
+        lib.mvl_car_status.argtypes = [vp]
+        lib.mvl_car_all_reduce.argtypes = [ctypes.POINTER(vp)] * 3 + [
+            ctypes.c_int, ctypes.c_int, vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp]
+        self._hbytes = lib.mvl_car_ipc_handle_bytes()
+        torch.cuda.set_device(device)
+        # flags, staging, result: fine-grained (uncached) allocations, coherent across the GPUs
+        sizes = [lib.mvl_car_flags_bytes(), max_bytes, max_bytes]
+        self._own: List[int] = []
+        handles = []
+        for nbytes in sizes:
+            p = vp()
+            self._ck(lib.mvl_car_alloc(ctypes.byref(p), nbytes, 1), "alloc")
+            self._own.append(p.value)
+            buf = ctypes.create_string_buffer(self._hbytes)
+            self._ck(lib.mvl_car_ipc_get(p, buf), "ipc_get")
+            handles.append(buf.raw)
+        everyone: List[Optional[list]] = [None] * world_size
+        dist.all_gather_object(everyone, handles, group=group)
+        self._mapped: List[int] = []
+        tables = []
+        for k in range(3):
+            arr = (vp * world_size)()
+            for r in range(world_size):
+                if r == rank:
+                    arr[r] = self._own[k]
+                else:
+                    q = vp()
+                    self._ck(lib.mvl_car_ipc_open(everyone[r][k], ctypes.byref(q)), "ipc_open")
+                    self._mapped.append(q.value)
+                    arr[r] = q.value
+            tables.append(arr)
+        self._flags, self._stage, self._result = tables
+        torch.cuda.synchronize()
+        dist.barrier(group=group)            # nobody launches before every mapping exists
+        self.calls = 0
+
+    @staticmethod
+    def _ck(rc: int, what: str) -> None:
+        if rc != 0:
+            raise RuntimeError(f"custom all-reduce: {what} failed with HIP error {rc}")
+
+    def fits(self, x: torch.Tensor) -> bool:
+        n = x.numel()
+        return (x.is_cuda and x.dtype in (torch.bfloat16, torch.float16) and x.is_contiguous()
+                and 0 < n * 2 <= self.max_bytes and n % (8 * self.world) == 0
+                and x.data_ptr() % 16 == 0)
+
+    def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
+        """In-place sum over the group; every rank ends with bit-identical values."""
+        two_shot = x.numel() * 2 > ONE_SHOT_MAX_BYTES
+        rc = self._lib.mvl_car_all_reduce(
+            self._flags, self._stage, self._result, self.world, self.rank, x.data_ptr(),
+            x.numel(), int(two_shot), 0 if x.dtype == torch.bfloat16 else 1,
+            torch.cuda.current_stream().cuda_stream)
+        self._ck(rc, "launch")
+        self.calls += 1
+        return x
+
+    def healthy(self) -> bool:
+        """False once any barrier of any call gave up waiting for a peer (synchronises)."""
+        torch.cuda.synchronize()
+        return self._lib.mvl_car_status(self._own[0]) == 0
+
+    def close(self) -> None:
+        if not self._own:
+            return
+        torch.cuda.synchronize()
+        try:
+            dist.barrier(group=self.group)   # peers may still be reading this rank's buffers
+        except Exception:
+            pass
+        for p in self._mapped:
+            self._lib.mvl_car_ipc_close(p)
+        for p in self._own:
+            self._lib.mvl_car_free(p)
+        self._mapped, self._own = [], []

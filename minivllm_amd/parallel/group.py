@@ -26,6 +26,8 @@ _OWNS_DEFAULT_GROUP = False
 # memory HERE - copy to the host, CPU collective, copy back - instead of by gloo's own
 # device-tensor path, which can deadlock when two processes share one GPU.  Never set with RCCL.
 _HOST_STAGED = False
+# optional peer-to-peer all-reduce for decode-sized tensors (parallel/custom_allreduce.py)
+_CUSTOM_AR = None
 
 
 def tp_rank() -> int:
@@ -88,6 +90,36 @@ def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
     _HOST_STAGED = on_gpu and dist.get_backend(_TP_GROUP) == "gloo"
 
 
+def enable_custom_all_reduce(device, max_bytes: Optional[int] = None) -> bool:
+    """Route all-reduces of tensors that fit through the peer-to-peer kernel.  Collective call:
+    every rank of the group must make it.  Returns False (and keeps RCCL) when the group size is
+    not 2/4/8 or the set-up fails on ANY rank."""
+    global _CUSTOM_AR
+    if _TP_GROUP is None or _TP_SIZE not in (2, 4, 8) or _CUSTOM_AR is not None:
+        return _CUSTOM_AR is not None
+    from .custom_allreduce import DEFAULT_MAX_BYTES, CustomAllReduce
+    car, err = None, None
+    try:
+        car = CustomAllReduce(_TP_GROUP, _TP_RANK, _TP_SIZE, torch.device(device),
+                              max_bytes or DEFAULT_MAX_BYTES)
+    except Exception as e:                     # e.g. IPC not permitted between these devices
+        err = e
+    ok = [None] * _TP_SIZE
+    dist.all_gather_object(ok, err is None, group=_TP_GROUP)
+    if all(ok):
+        _CUSTOM_AR = car
+        return True
+    if car is not None:
+        car.close()
+    if _TP_RANK == 0:
+        print(f"[tp] peer-to-peer all-reduce unavailable ({err}); using the backend's", flush=True)
+    return False
+
+
+def custom_all_reduce():
+    return _CUSTOM_AR
+
+
 def set_tp_for_testing(rank: int, world_size: int) -> None:
     """Shard-math tests build layers for an arbitrary (rank, size) without any
     communication backend."""
@@ -96,7 +128,10 @@ def set_tp_for_testing(rank: int, world_size: int) -> None:
 
 
 def destroy_tensor_parallel() -> None:
-    global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP
+    global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP, _CUSTOM_AR
+    if _CUSTOM_AR is not None:
+        _CUSTOM_AR.close()
+        _CUSTOM_AR = None
     keep = os.environ.get("MINIVLLM_KEEP_PG") == "1"      # another engine will reuse it
     if _TP_GROUP is not None and _OWNS_DEFAULT_GROUP and dist.is_initialized() and not keep:
         dist.destroy_process_group()
@@ -110,6 +145,8 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     """In-place sum over the TP group; returns ``x`` (the reference returns the
     collective's return value instead of the tensor: layers/linear.py:218-219)."""
     if _TP_GROUP is not None:
+        if _CUSTOM_AR is not None and _CUSTOM_AR.fits(x):
+            return _CUSTOM_AR.all_reduce(x)
         if _HOST_STAGED and x.is_cuda:
             h = x.cpu()
             dist.all_reduce(h, group=_TP_GROUP)

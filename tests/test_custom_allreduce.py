@@ -1,0 +1,85 @@
+"""Peer-to-peer all-reduce kernel: two ranks share the one GPU of the test box and map each
+other's buffers through HIP IPC handles (on a node the peers are other GPUs over xGMI; the flag
+protocol, the one-/two-shot data paths and graph replay are the same)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    from minivllm_amd.parallel.custom_allreduce import ONE_SHOT_MAX_BYTES, CustomAllReduce
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                                world_size=world)
+        car = CustomAllReduce(dist.group.WORLD, rank, world, torch.device("cuda", 0),
+                              max_bytes=4 << 20)
+        worst = 0.0
+        sizes = [16, 4096, ONE_SHOT_MAX_BYTES // 2, ONE_SHOT_MAX_BYTES // 2 + 16,
+                 256 * 4096, 2 << 20]                      # elements; both sides of the switch
+        for dtype in (torch.bfloat16, torch.float16):
+            for n in sizes:
+                assert n % (8 * world) == 0
+                g = torch.Generator(device="cuda").manual_seed(1000 * rank + n % 977)
+                x = torch.randn(n, device="cuda", dtype=dtype, generator=g)
+                assert car.fits(x)
+                mine = x.float().cpu()
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                want = sum(parts)
+                got = car.all_reduce(x).float().cpu()
+                worst = max(worst, float((got - want).abs().max() / (want.abs().max() + 1e-6)))
+        # graph replay: three calls of different sizes in one graph, replayed on fresh inputs
+        bufs = [torch.zeros(n, device="cuda", dtype=torch.bfloat16) for n in (4096, 256 * 4096, 64)]
+        for b in bufs:
+            car.all_reduce(b)                                # warm-up outside capture
+        torch.cuda.synchronize()
+        dist.barrier()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for b in bufs:
+                car.all_reduce(b)
+        graph_ok = True
+        for it in range(3):
+            for b in bufs:
+                b.fill_(float(rank + 1 + it))
+            torch.cuda.synchronize()
+            dist.barrier()
+            g.replay()
+            torch.cuda.synchronize()
+            expect = float(sum(r + 1 + it for r in range(world)))
+            graph_ok &= all(bool((b.float() == expect).all()) for b in bufs)
+            dist.barrier()
+        healthy = car.healthy()
+        assert not car.fits(torch.zeros(24, device="cuda", dtype=torch.float32))
+        car.close()
+        dist.destroy_process_group()
+        q.put((rank, worst, graph_ok, healthy, None))
+    except Exception as e:                                   # report instead of hanging the peer
+        import traceback
+        q.put((rank, None, False, False, traceback.format_exc()))
+
+
+def test_two_ranks_on_one_gpu_match_the_sum():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + os.getpid() % 300
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=150) for _ in procs]
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.terminate()
+    for rank, worst, graph_ok, healthy, err in res:
+        assert err is None, err
+        assert worst < 1e-2, (rank, worst)               # one bf16 rounding of the fp32 sum
+        assert graph_ok and healthy
