@@ -371,10 +371,13 @@ def main():
                **_round(tp["main"]), "data_parallel_replicas": dp}
         if tp.get("second"):
             out["secondary"] = {"model": args.second_model, **_round(tp["second"])}
+        if tpc is not None:
+            out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
     else:
         out = {"metric": metric, "value": 0.0, **base, "ms_per_step": None, "scaling": "weak",
                "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}"},
-               "data_parallel_replicas": dp, "tensor_parallel": tp}
+               "data_parallel_replicas": dp, "tensor_parallel": tp,
+               "tensor_parallel_p2p_allreduce": tpc}
     print(json.dumps(out), flush=True)
     if not (ok(dp) or ok(tp)):
         sys.exit(1)

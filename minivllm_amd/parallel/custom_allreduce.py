@@ -50,33 +50,59 @@ class CustomAllReduce:
         # flags, staging, result: fine-grained (uncached) allocations, coherent across the GPUs
         sizes = [lib.mvl_car_flags_bytes(), max_bytes, max_bytes]
         self._own: List[int] = []
-        handles = []
-        for nbytes in sizes:
-            p = vp()
-            self._ck(lib.mvl_car_alloc(ctypes.byref(p), nbytes, 1), "alloc")
-            self._own.append(p.value)
-            buf = ctypes.create_string_buffer(self._hbytes)
-            self._ck(lib.mvl_car_ipc_get(p, buf), "ipc_get")
-            handles.append(buf.raw)
-        everyone: List[Optional[list]] = [None] * world_size
-        dist.all_gather_object(everyone, handles, group=group)
         self._mapped: List[int] = []
+        handles, err = [], None
+        try:
+            for nbytes in sizes:
+                p = vp()
+                self._ck(lib.mvl_car_alloc(ctypes.byref(p), nbytes, 1), "alloc")
+                self._own.append(p.value)
+                buf = ctypes.create_string_buffer(self._hbytes)
+                self._ck(lib.mvl_car_ipc_get(p, buf), "ipc_get")
+                handles.append(buf.raw)
+        except Exception as e:
+            err = repr(e)
+        # every rank takes part in both exchanges whatever happened locally, and all ranks give
+        # up together: a rank that raised on its own would leave the others in a collective
+        everyone = self._exchange((err, handles))
+        self._raise_if_any_failed([e for e, _ in everyone])
         tables = []
-        for k in range(3):
-            arr = (vp * world_size)()
-            for r in range(world_size):
-                if r == rank:
-                    arr[r] = self._own[k]
-                else:
-                    q = vp()
-                    self._ck(lib.mvl_car_ipc_open(everyone[r][k], ctypes.byref(q)), "ipc_open")
-                    self._mapped.append(q.value)
-                    arr[r] = q.value
-            tables.append(arr)
+        try:
+            for k in range(3):
+                arr = (vp * world_size)()
+                for r in range(world_size):
+                    if r == rank:
+                        arr[r] = self._own[k]
+                    else:
+                        q = vp()
+                        self._ck(lib.mvl_car_ipc_open(everyone[r][1][k], ctypes.byref(q)), "ipc_open")
+                        self._mapped.append(q.value)
+                        arr[r] = q.value
+                tables.append(arr)
+            torch.cuda.synchronize()
+        except Exception as e:
+            err = repr(e)
+        self._raise_if_any_failed(self._exchange(err))   # also: every mapping exists from here on
         self._flags, self._stage, self._result = tables
-        torch.cuda.synchronize()
-        dist.barrier(group=group)            # nobody launches before every mapping exists
         self.calls = 0
+
+    def _exchange(self, obj) -> list:
+        out: List[Optional[object]] = [None] * self.world
+        dist.all_gather_object(out, obj, group=self.group)
+        return out
+
+    def _raise_if_any_failed(self, errors: list) -> None:
+        bad = [(r, e) for r, e in enumerate(errors) if e is not None]
+        if bad:
+            self._release()
+            raise RuntimeError(f"peer-to-peer all-reduce set-up failed on rank(s) {bad}")
+
+    def _release(self) -> None:
+        for p in self._mapped:
+            self._lib.mvl_car_ipc_close(p)
+        for p in self._own:
+            self._lib.mvl_car_free(p)
+        self._mapped, self._own = [], []
 
     @staticmethod
     def _ck(rc: int, what: str) -> None:
@@ -106,15 +132,13 @@ class CustomAllReduce:
         return self._lib.mvl_car_status(self._own[0]) == 0
 
     def close(self) -> None:
+        """Collective: every rank of the group calls it (peers may still be reading this rank's
+        buffers until all have arrived)."""
         if not self._own:
             return
         torch.cuda.synchronize()
         try:
-            dist.barrier(group=self.group)   # peers may still be reading this rank's buffers
+            dist.barrier(group=self.group)
         except Exception:
             pass
-        for p in self._mapped:
-            self._lib.mvl_car_ipc_close(p)
-        for p in self._own:
-            self._lib.mvl_car_free(p)
-        self._mapped, self._own = [], []
+        self._release()

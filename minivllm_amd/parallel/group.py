@@ -98,22 +98,16 @@ def enable_custom_all_reduce(device, max_bytes: Optional[int] = None) -> bool:
     if _TP_GROUP is None or _TP_SIZE not in (2, 4, 8) or _CUSTOM_AR is not None:
         return _CUSTOM_AR is not None
     from .custom_allreduce import DEFAULT_MAX_BYTES, CustomAllReduce
-    car, err = None, None
     try:
-        car = CustomAllReduce(_TP_GROUP, _TP_RANK, _TP_SIZE, torch.device(device),
-                              max_bytes or DEFAULT_MAX_BYTES)
-    except Exception as e:                     # e.g. IPC not permitted between these devices
-        err = e
-    ok = [None] * _TP_SIZE
-    dist.all_gather_object(ok, err is None, group=_TP_GROUP)
-    if all(ok):
-        _CUSTOM_AR = car
+        # the constructor fails on every rank or on none (it exchanges its own status)
+        _CUSTOM_AR = CustomAllReduce(_TP_GROUP, _TP_RANK, _TP_SIZE, torch.device(device),
+                                     max_bytes or DEFAULT_MAX_BYTES)
         return True
-    if car is not None:
-        car.close()
-    if _TP_RANK == 0:
-        print(f"[tp] peer-to-peer all-reduce unavailable ({err}); using the backend's", flush=True)
-    return False
+    except RuntimeError as e:                  # e.g. IPC not permitted between these devices
+        if _TP_RANK == 0:
+            print(f"[tp] peer-to-peer all-reduce unavailable ({e}); using the backend's",
+                  flush=True)
+        return False
 
 
 def custom_all_reduce():

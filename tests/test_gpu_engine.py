@@ -116,7 +116,8 @@ def test_sampling_temperature_runs(gpu):
     e.exit()
 
 
-def test_tp2_on_one_gpu_matches_tp1(gpu):
+@pytest.mark.parametrize("p2p_allreduce", [False, True])
+def test_tp2_on_one_gpu_matches_tp1(gpu, p2p_allreduce):
     """Both TP ranks share cuda:0 and talk through gloo, staged through host memory by
     parallel/group.py (RCCL refuses two ranks on one device): exercises the sharded HIP path,
     the shard-wise sampler + (value, index) exchange, and the control channel.  Eager only:
@@ -129,9 +130,14 @@ def test_tp2_on_one_gpu_matches_tp1(gpu):
     want = one.generate(prompts, sp)["token_ids"]
     one.exit()
     port = 29700 + os.getpid() % 200
-    two = LLMEngine(_cfg(world_size=2, dist_backend="gloo", master_port=port,
-                         gpu_memory_utilization=0.3))
+    two = LLMEngine(_cfg(world_size=2, dist_backend="gloo", master_port=port + int(p2p_allreduce),
+                         gpu_memory_utilization=0.3, custom_all_reduce=p2p_allreduce))
+    if p2p_allreduce:                    # row-parallel outputs go through the peer-to-peer kernel
+        from minivllm_amd.parallel import group as pg
+        assert pg.custom_all_reduce() is not None
     got = two.generate(prompts, sp)["token_ids"]
+    if p2p_allreduce:
+        assert pg.custom_all_reduce().calls > 0 and pg.custom_all_reduce().healthy()
     two.exit()
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
