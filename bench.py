@@ -126,6 +126,9 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
         return rng.integers(0, vocab, size=(n, length)).tolist()
 
     res = {"init_s": round(init_s, 1), "kv_blocks": eng.model_runner.num_kv_blocks}
+    if not replicas and world > 1:
+        from minivllm_amd.parallel import group as pg
+        res["p2p_allreduce"] = pg.custom_all_reduce() is not None
 
     # ------------------------------------------------------------ prefill phase
     if args.mode in ("both", "prefill"):

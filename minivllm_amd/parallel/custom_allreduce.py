@@ -126,6 +126,22 @@ class CustomAllReduce:
         self.calls += 1
         return x
 
+    def self_test(self) -> bool:
+        """All-reduce known integer patterns through both data paths and compare with the exact
+        sums (collective call; the result is this rank's own verdict)."""
+        P, ok = self.world, True
+        for n in (8 * P * 16, (ONE_SHOT_MAX_BYTES // 2 + 8 * P * 64)):
+            n -= n % (8 * P)
+            if n * 2 > self.max_bytes:
+                continue
+            base = (torch.arange(n, device=self.device) % 7).to(torch.bfloat16)
+            for _ in range(2):                                  # twice: epochs advance
+                x = base + float(self.rank)
+                self.all_reduce(x)
+                want = base.float() * P + P * (P - 1) / 2
+                ok = ok and bool((x.float() == want).all())
+        return ok and self.healthy()
+
     def healthy(self) -> bool:
         """False once any barrier of any call gave up waiting for a peer (synchronises)."""
         torch.cuda.synchronize()

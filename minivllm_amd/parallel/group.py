@@ -100,8 +100,14 @@ def enable_custom_all_reduce(device, max_bytes: Optional[int] = None) -> bool:
     from .custom_allreduce import DEFAULT_MAX_BYTES, CustomAllReduce
     try:
         # the constructor fails on every rank or on none (it exchanges its own status)
-        _CUSTOM_AR = CustomAllReduce(_TP_GROUP, _TP_RANK, _TP_SIZE, torch.device(device),
-                                     max_bytes or DEFAULT_MAX_BYTES)
+        car = CustomAllReduce(_TP_GROUP, _TP_RANK, _TP_SIZE, torch.device(device),
+                              max_bytes or DEFAULT_MAX_BYTES)
+        verdicts = [None] * _TP_SIZE
+        dist.all_gather_object(verdicts, car.self_test(), group=_TP_GROUP)
+        if not all(verdicts):                  # wrong sums or a timed-out barrier on some rank
+            car.close()
+            raise RuntimeError(f"self-test failed (per-rank verdicts {verdicts})")
+        _CUSTOM_AR = car
         return True
     except RuntimeError as e:                  # e.g. IPC not permitted between these devices
         if _TP_RANK == 0:

@@ -18,6 +18,7 @@ def _worker(rank, world, port, q):
                                 world_size=world)
         car = CustomAllReduce(dist.group.WORLD, rank, world, torch.device("cuda", 0),
                               max_bytes=4 << 20)
+        assert car.self_test()
         worst = 0.0
         sizes = [16, 4096, ONE_SHOT_MAX_BYTES // 2, ONE_SHOT_MAX_BYTES // 2 + 16,
                  256 * 4096, 2 << 20]                      # elements; both sides of the switch
