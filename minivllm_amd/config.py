@@ -100,7 +100,7 @@ _MODEL_KEYS = {f.name for f in fields(ModelConfig)}
 
 @dataclass
 class EngineConfig:
-    """Everything the engine, scheduler and runner need (reference keys: SURVEY of main.py:15-41)."""
+    """Everything the engine, scheduler and runner need (reference keys: main.py:15-41)."""
     model: ModelConfig = field(default_factory=ModelConfig)
     # scheduler budgets
     max_num_sequences: int = 256

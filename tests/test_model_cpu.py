@@ -65,7 +65,7 @@ def test_prefill_logits_match_hf_qwen3(tied):
 
 
 def test_engine_greedy_generation_matches_hf_generate():
-    """BASELINE plumbing config: tiny Qwen3, CPU, greedy, through LLMEngine.generate with a
+    """Plumbing configuration: tiny Qwen3, CPU, greedy, through LLMEngine.generate with a
     small KV block so that decode crosses block boundaries."""
     from minivllm_amd.engine.llm_engine import LLMEngine
     cfg = tiny_cfg()
