@@ -131,6 +131,9 @@ class EngineConfig:
     # first GPU of this engine's tensor-parallel group when LOCAL_RANK is not set by a launcher
     # (data-parallel replicas started from one process each take their own range of devices)
     device_base: int = 0
+    # let a prompt longer than the step's token budget be prefetched over several steps (the
+    # reference can never schedule such a prompt)
+    enable_chunked_prefill: bool = True
     # all-reduce decode-sized tensors with the peer-to-peer kernel (parallel/custom_allreduce.py)
     # instead of RCCL; larger tensors still go to RCCL.  Also switched on by MINIVLLM_CUSTOM_AR=1.
     custom_all_reduce: bool = False

@@ -79,7 +79,8 @@ class LLMEngine:
         self.model_runner = ModelRunner(cfg, 0)
         self.scheduler = Scheduler(cfg.max_num_sequences, cfg.max_num_batched_tokens,
                                    self.model_runner.num_kv_blocks, cfg.block_size, cfg.eos,
-                                   max_model_length=cfg.max_model_length)
+                                   max_model_length=cfg.max_model_length,
+                                   enable_chunked_prefill=cfg.enable_chunked_prefill)
         self.tokenizer = load_tokenizer(cfg.model_name_or_path, cfg.model.vocab_size)
         self.stats = EngineStats()
         self._exited = False
@@ -132,7 +133,7 @@ class LLMEngine:
             return [], 0, False
         self._check_workers()
         if is_prefill:
-            num_tokens = sum(len(s) - s.num_cached_tokens for s in seqs)
+            num_tokens = sum(s.num_scheduled_prefill_tokens for s in seqs)
         else:
             num_tokens = len(seqs)
         token_ids = self.model_runner.run(seqs, is_prefill)

@@ -330,7 +330,8 @@ class ModelRunner:
         max_q = max_k = 0
         has_prefix = False
         for seq in seqs:
-            start, end = seq.num_cached_tokens, seq.num_tokens
+            start = seq.num_cached_tokens
+            end = seq.num_tokens if seq.prefill_end is None else seq.prefill_end
             has_prefix |= start > 0
             p = np.arange(start, end, dtype=np.int32)
             bt = np.asarray(seq.block_table, dtype=np.int32)

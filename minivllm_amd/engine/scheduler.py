@@ -9,6 +9,13 @@ relative to the reference: sampled tokens go through ``Sequence.append_token`` s
 lengths advance and ``max_tokens`` triggers; a decode candidate that does not fit
 the step's budget stays in the running queue instead of being dropped; prompts
 that can never be scheduled are rejected when they are added.
+
+Beyond the reference (which can never schedule a prompt longer than
+``max_num_batched_tokens``, scheduler.py:31,38-39): chunked prefill.  The last sequence
+admitted in a prefill step may receive only the tokens the step's budget still has room
+for; it then waits in ``prefilling`` and later prefill steps continue it, attending to its
+own earlier chunks through the paged cache, before anything new is admitted.  Only the chunk
+that reaches the end of the sequence yields a sampled token.
 """
 from __future__ import annotations
 
@@ -22,7 +29,10 @@ from .sequence import Sequence, SequenceStatus
 class Scheduler:
     def __init__(self, max_num_sequences: int, max_num_batched_tokens: int,
                  max_cached_blocks: int, block_size: int, eos: int,
-                 max_model_length: Optional[int] = None):
+                 max_model_length: Optional[int] = None, enable_chunked_prefill: bool = True):
+        self.enable_chunked_prefill = enable_chunked_prefill
+        # admitted (blocks allocated) but not yet completely prefetched, oldest first
+        self.prefilling: Deque[Sequence] = deque()
         self.block_manager = make_block_manager(max_cached_blocks, block_size)
         self.max_num_sequences = max_num_sequences
         self.max_num_batched_tokens = max_num_batched_tokens
@@ -40,7 +50,7 @@ class Scheduler:
         self._plain_decode_steps = 0
 
     def is_finished(self) -> bool:
-        return not self.waiting and not self.running
+        return not self.waiting and not self.running and not self.prefilling
 
     def add_sequence(self, seq: Sequence) -> None:
         seq.block_size = self.block_size
@@ -48,7 +58,7 @@ class Scheduler:
         # a preempted sequence is re-prefetched with its generated tokens, so the
         # whole request (prompt + max_tokens) must fit one prefill step
         worst = seq.num_prompt_tokens + seq.max_tokens
-        if seq.num_prompt_tokens > limit:
+        if seq.num_prompt_tokens > limit and not self.enable_chunked_prefill:
             raise ValueError(
                 f"prompt of {seq.num_prompt_tokens} tokens exceeds max_num_batched_tokens={limit}")
         if self.max_model_length is not None and worst > self.max_model_length:
@@ -68,16 +78,29 @@ class Scheduler:
         num_tokens = 0
         bm = self.block_manager
 
-        # phase 1: admit waiting sequences (prefill) in arrival order
-        while self.waiting and len(scheduled) < self.max_num_sequences:
+        budget = self.max_num_batched_tokens
+        # phase 0: continue sequences whose prefill was cut by an earlier step's budget
+        while self.prefilling and len(scheduled) < self.max_num_sequences and num_tokens < budget:
+            seq = self.prefilling[0]
+            take = min(len(seq) - seq.num_cached_tokens, budget - num_tokens)
+            seq.prefill_end = seq.num_cached_tokens + take
+            scheduled.append(seq)
+            num_tokens += take
+            if seq.prefill_end < len(seq):
+                break                                   # budget exhausted, still not complete
+            self.prefilling.popleft()
+            self.running.append(seq)
+
+        # phase 1: admit waiting sequences (prefill) in arrival order.  Nothing new is admitted
+        # while an older sequence is still incomplete after this step: a newcomer could hit its
+        # prefix-cache blocks before their KV exists.
+        while (self.waiting and not self.prefilling and len(scheduled) < self.max_num_sequences):
             seq = self.waiting[0]
-            if num_tokens + len(seq) > self.max_num_batched_tokens and scheduled:
+            fits = num_tokens + len(seq) <= budget
+            # a cut sequence gets at least one KV block worth of tokens now, or waits
+            room = budget - num_tokens >= min(len(seq), self.block_size)
+            if not fits and scheduled and not (self.enable_chunked_prefill and room):
                 break
-            if len(seq) > self.max_num_batched_tokens:
-                # grew past one step's budget while it was running and was then
-                # preempted; let it through alone rather than stall forever
-                if scheduled:
-                    break
             if not bm.can_allocate(seq):
                 break
             if len(self.running) >= self.max_num_sequences:
@@ -85,9 +108,19 @@ class Scheduler:
             self.waiting.popleft()
             bm.allocate(seq)
             seq.status = SequenceStatus.RUNNING
-            self.running.append(seq)
+            todo = len(seq) - seq.num_cached_tokens
+            take = todo
+            if self.enable_chunked_prefill:
+                take = min(todo, budget - num_tokens)
+            # without chunking an over-long sequence (grew while running, then preempted) goes
+            # through alone rather than stall forever
+            seq.prefill_end = seq.num_cached_tokens + take
             scheduled.append(seq)
-            num_tokens += len(seq) - seq.num_cached_tokens
+            num_tokens += take
+            if seq.prefill_end < len(seq):
+                self.prefilling.append(seq)
+                break
+            self.running.append(seq)
         if scheduled:
             self._decode_batch = None
             return scheduled, True
@@ -137,6 +170,7 @@ class Scheduler:
 
     def preempt(self, seq: Sequence) -> None:
         self._decode_batch = None
+        seq.prefill_end = None
         self.block_manager.deallocate(seq)
         seq.status = SequenceStatus.WAITING
         self.waiting.appendleft(seq)
@@ -146,6 +180,12 @@ class Scheduler:
     def postprocess(self, seqs: List[Sequence], token_ids: List[int]) -> List[Sequence]:
         finished = []
         for seq, token_id in zip(seqs, token_ids):
+            if seq.prefill_end is not None:
+                end, seq.prefill_end = seq.prefill_end, None
+                if end < seq.num_tokens:
+                    # partial prefill chunk: its KV is in the cache now, nothing was generated
+                    seq.num_cached_tokens = end
+                    continue
             seq.append_token(int(token_id))
             hit_eos = (not seq.ignore_eos) and token_id == self.eos
             hit_len = seq.num_completion_tokens >= seq.max_tokens

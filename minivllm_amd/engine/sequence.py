@@ -27,6 +27,9 @@ class SequenceStatus(Enum):
 class Sequence:
     counter = count()
     block_size = 256          # default when none is given; the engine always passes its own
+    # chunked prefill: the prefill step scheduled now covers tokens [num_cached_tokens,
+    # prefill_end); None = up to the end of the sequence
+    prefill_end: Optional[int] = None
 
     def __init__(self, token_ids: List[int], sampling_params: Optional[SamplingParams] = None,
                  block_size: Optional[int] = None):
@@ -85,6 +88,12 @@ class Sequence:
         if not 0 <= i < self.num_blocks:
             raise IndexError(f"block index {i} out of range [0, {self.num_blocks})")
         return self.token_ids[i * self.block_size:(i + 1) * self.block_size]
+
+    @property
+    def num_scheduled_prefill_tokens(self) -> int:
+        """Tokens the scheduled prefill step computes for this sequence."""
+        end = self.num_tokens if self.prefill_end is None else self.prefill_end
+        return end - self.num_cached_tokens
 
     def append_token(self, token_id: int) -> None:
         self.token_ids.append(token_id)

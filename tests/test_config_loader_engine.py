@@ -127,6 +127,28 @@ def test_preemption_recompute_keeps_outputs_and_frees_everything():
     assert got == want
 
 
+def test_chunked_prefill_matches_whole_prompt_prefill():
+    """Prompts longer than a step's token budget are prefetched over several steps (each chunk
+    attends to the earlier ones through the paged cache); tokens equal the one-step prefill."""
+    rng = np.random.default_rng(8)
+    shared = rng.integers(0, 400, size=24).tolist()
+    prompts = [rng.integers(0, 400, size=n).tolist() for n in (70, 9, 45)] + \
+              [shared + rng.integers(0, 400, size=n).tolist() for n in (30, 5)]
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    whole = _engine()
+    want = whole.generate(prompts, sp)["token_ids"]
+    steps_whole = whole.stats.prefill_steps
+    whole.exit()
+    chunked = _engine(max_num_batched_tokens=32)
+    got = chunked.generate(prompts, sp)["token_ids"]
+    assert chunked.stats.prefill_steps > steps_whole
+    assert chunked.stats.prefill_tokens <= sum(map(len, prompts))    # no token computed twice
+    chunked.exit()
+    assert got == want
+    with pytest.raises(ValueError):                                  # reference policy: rejected
+        _engine(max_num_batched_tokens=32, enable_chunked_prefill=False).add_prompt(prompts[0], sp)
+
+
 def test_engine_api_surface_and_stop_conditions():
     eng = _engine(eos=7)
     s = eng.add_prompt([1, 2, 3], SamplingParams(temperature=0, max_tokens=5))

@@ -165,3 +165,23 @@ def test_rccl_collectives_inside_decode_graphs(gpu):
     forced.exit()
     assert not pg.collectives_active()
     assert got == want
+
+
+def test_chunked_prefill_on_gpu_matches_whole_prefill(gpu):
+    """A 128-token step budget cuts prompts of up to 400 tokens into chunks; every later chunk
+    attends to the earlier ones through the paged-KV prefill kernel (q_len < k_len)."""
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    prompts = _prompts(5, lo=150, hi=400, seed=9)
+    sp = SamplingParams(temperature=0, max_tokens=16, ignore_eos=True)
+    whole = LLMEngine(_cfg())
+    want = whole.generate(prompts, sp)["token_ids"]
+    n_whole = whole.stats.prefill_steps
+    whole.exit()
+    cut = LLMEngine(_cfg(max_num_batched_tokens=128))
+    got = cut.generate(prompts, sp)["token_ids"]
+    assert cut.stats.prefill_steps >= 2 * n_whole
+    assert cut.stats.prefill_tokens == sum(map(len, prompts))
+    cut.exit()
+    same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
+    total = sum(len(x) for x in want)
+    assert same / total > 0.9, (same, total)

@@ -161,8 +161,10 @@ def test_compute_hash_is_chained_and_stable():
 
 
 # ----------------------------------------------------------------- Scheduler
-def make_sched(blocks=64, max_seqs=4, max_tokens=32, eos=999, max_len=None):
-    return Scheduler(max_seqs, max_tokens, blocks, BS, eos, max_model_length=max_len)
+def make_sched(blocks=64, max_seqs=4, max_tokens=32, eos=999, max_len=None, chunked=False):
+    """chunked=False is the reference policy (a prompt is prefetched whole or not at all)."""
+    return Scheduler(max_seqs, max_tokens, blocks, BS, eos, max_model_length=max_len,
+                     enable_chunked_prefill=chunked)
 
 
 def test_prefill_has_priority_and_respects_budgets():
@@ -241,3 +243,60 @@ def test_unschedulable_requests_are_rejected_up_front():
     big = make_sched(blocks=2, max_tokens=64)
     with pytest.raises(ValueError):
         big.add_sequence(seq(range(8), max_tokens=8))          # needs 4 blocks, cache has 2
+
+
+# ------------------------------------------------------------ chunked prefill
+def test_long_prompt_is_prefetched_in_chunks_and_samples_once():
+    sch = make_sched(max_tokens=8, chunked=True)               # BS = 4, 8 tokens per step
+    a = seq(range(21), max_tokens=3)
+    sch.add_sequence(a)                                        # longer than a step: accepted
+    spans = []
+    for _ in range(3):
+        batch, is_prefill = sch.schedule()
+        assert is_prefill and batch == [a]
+        spans.append((a.num_cached_tokens, a.prefill_end))
+        done = sch.postprocess(batch, [777])
+        assert done == []
+    assert spans == [(0, 8), (8, 16), (16, 21)]
+    assert a.completion_token_ids == [777] and a.num_tokens == 22   # only the last chunk sampled
+    assert not sch.prefilling and list(sch.running) == [a]
+    batch, is_prefill = sch.schedule()
+    assert not is_prefill and batch == [a]
+
+
+def test_chunk_fills_the_rest_of_the_budget_and_blocks_new_admissions():
+    sch = make_sched(max_tokens=16, chunked=True)
+    a, b, c = seq(range(10)), seq(range(100, 118)), seq(range(200, 203))
+    for s in (a, b, c):
+        sch.add_sequence(s)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == [a, b]
+    assert (b.num_cached_tokens, b.prefill_end) == (0, 6)      # 16 - 10 tokens left for b
+    assert list(sch.prefilling) == [b] and list(sch.running) == [a]
+    sch.postprocess(batch, [1, 999])
+    assert a.num_tokens == 11 and b.num_tokens == 18 and b.num_cached_tokens == 6
+    batch, is_prefill = sch.schedule()                          # b completes, then c is admitted
+    assert is_prefill and batch == [b, c] and b.prefill_end == 18
+    sch.postprocess(batch, [2, 3])
+    assert b.completion_token_ids == [2] and c.completion_token_ids == [3]
+    assert not sch.prefilling and list(sch.running) == [a, b, c]
+
+
+def test_a_cut_sequence_needs_room_for_one_block():
+    sch = make_sched(max_tokens=16, chunked=True)
+    a, b = seq(range(14)), seq(range(100, 120))
+    sch.add_sequence(a); sch.add_sequence(b)
+    batch, _ = sch.schedule()
+    assert batch == [a]                                        # 2 tokens of room < one block of 4
+
+
+def test_preempting_drops_chunk_state():
+    sch = make_sched(max_tokens=8, chunked=True)
+    a = seq(range(12))
+    sch.add_sequence(a)
+    batch, _ = sch.schedule()
+    sch.postprocess(batch, [0])
+    assert a.num_cached_tokens == 8 and list(sch.prefilling) == [a]
+    sch.prefilling.clear()
+    sch.preempt(a)
+    assert a.prefill_end is None and a.num_cached_tokens == 0 and a.block_table == []
