@@ -72,7 +72,7 @@ def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scal
 def linear(x, weight, bias=None):
     """``x @ weight.T (+ bias)``: the library GEMM, except for decode-sized GPU inputs of the
     shapes where the hand-written weight-streaming kernel is faster."""
-    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 8:
+    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 16:
         h = _hip()
         if h.skinny_gemm_pays(x, weight):
             return h.skinny_linear(x, weight, bias)
@@ -82,7 +82,7 @@ def linear(x, weight, bias=None):
 def swiglu_linear(x, weight, bias=None):
     """``silu(x @ Wg.T) * (x @ Wu.T)`` for the fused ``[Wg; Wu]`` weight: one kernel for
     decode-sized GPU inputs, otherwise GEMM + activation kernel."""
-    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 8:
+    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 16:
         h = _hip()
         if h.skinny_gemm_pays(x, weight, swiglu=True):
             return h.skinny_linear(x, weight, bias, swiglu=True)

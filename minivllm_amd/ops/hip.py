@@ -290,7 +290,7 @@ def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torc
 
 # ------------------------------------------------------- weight-streaming GEMM
 SKINNY_MAX_ROWS = 16
-SKINNY_PAYS_ROWS = 8                  # up to here the kernel beats the library (see skinny_gemm_pays)
+SKINNY_PAYS_ROWS = 16                 # up to here the kernel beats the library (see skinny_gemm_pays)
 SKINNY_MIN_WEIGHT_BYTES = 8 << 20     # below this a projection is launch-latency bound anyway
 
 
@@ -308,11 +308,12 @@ def skinny_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) 
 
 def skinny_gemm_pays(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
     """Whether the weight-streaming kernel is the faster choice for this call.  Measured against
-    the tuned library GEMM on MI355X (Qwen3-8B shapes, graph replay, tools/skinny_gemm_bench.py):
-    with <= 8 rows the fused SwiGLU form wins (one kernel instead of GEMM + activation, 40.8 vs
-    45.2 us at 1 row), and so does the plain form when the grid is a single round of workgroups
-    that each make one pass over K (N <= 4096, K <= 4096: 9.8 vs 12.0 us); longer K or more
-    column tiles go to the library, which then streams at ~4.6 TB/s."""
+    the library GEMM on MI355X (Qwen3-8B shapes, graph replay, weights streamed cold from HBM,
+    tools/skinny_gemm_bench.py, profiles/r1_skinny_gemm_vs_library.txt), 1 / 8 / 16 rows:
+    fused SwiGLU 35.9 / 39.0 / 42.5 us against 45.5 / 45.8 / 46.1 us for GEMM + activation;
+    o-projection (N = K = 4096) 8.3 / 9.4 / 10.9 us against 15.2 / 15.3 / 15.4 us.  With more
+    output columns or a longer K (QKV, down projection) the library is as fast or faster, so
+    those stay with it."""
     if x.dim() != 2 or x.shape[0] > SKINNY_PAYS_ROWS or not skinny_gemm_ok(x, weight, swiglu):
         return False
     n, k = weight.shape

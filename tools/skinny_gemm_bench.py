@@ -25,15 +25,26 @@ def bench(fn, x, ws):
     return (time.perf_counter() - t0) / (25 * len(ws))
 
 
+hip._lib.mvl_skinny_gemm_force_waves.restype = None
 for M in (1, 8, 16):
     for name, (N, K) in shapes.items():
         x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
-        ws = [torch.randn(N, K, device="cuda", dtype=torch.bfloat16) for _ in range(4)]
+        # enough copies that a pass over them cannot stay in the 256 MB Infinity Cache
+        copies = max(4, -(-(640 << 20) // (N * K * 2)))
+        ws = [torch.randn(N, K, device="cuda", dtype=torch.bfloat16) for _ in range(copies)]
         tl = bench(torch.nn.functional.linear, x, ws)
-        tk = bench(hip.skinny_linear, x, ws)
-        line = f"M={M:2d} {name:8s} library {tl*1e6:6.1f} us ({N*K*2/tl/1e12:4.2f} TB/s)  kernel {tk*1e6:6.1f} us ({N*K*2/tk/1e12:4.2f} TB/s)"
+        line = f"M={M:2d} {name:8s} library {tl*1e6:6.1f} us ({N*K*2/tl/1e12:4.2f} TB/s)  kernel"
+        for waves in (0, 8, 4):
+            hip._lib.mvl_skinny_gemm_force_waves(waves)
+            tk = bench(hip.skinny_linear, x, ws)
+            line += f"  w{waves or 'auto'} {tk*1e6:6.1f} us ({N*K*2/tk/1e12:4.2f})"
         if name == "gate_up":
-            tf = bench(lambda a, w: hip.skinny_linear(a, w, swiglu=True), x, ws)
             tlf = bench(lambda a, w: hip.silu_and_mul(torch.nn.functional.linear(a, w)), x, ws)
-            line += f" | fused SwiGLU: library+act {tlf*1e6:6.1f} us, kernel {tf*1e6:6.1f} us"
+            line += f" | fused SwiGLU: library+act {tlf*1e6:6.1f} us, kernel"
+            for waves in (0, 8, 4):
+                hip._lib.mvl_skinny_gemm_force_waves(waves)
+                tf = bench(lambda a, w: hip.skinny_linear(a, w, swiglu=True), x, ws)
+                line += f"  w{waves or 'auto'} {tf*1e6:6.1f}"
+        hip._lib.mvl_skinny_gemm_force_waves(0)
         print(line, flush=True)
+        del ws
