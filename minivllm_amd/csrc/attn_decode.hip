@@ -233,23 +233,40 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     }
 }
 
-// Merge the context splits: grid (Hq, B), D threads.
+// Merge the context splits: grid (Hq, B), D threads.  The (max, sum) pairs are fetched by
+// one lane each and the partial outputs with all loads of a group of 8 splits in flight at
+// once: the kernel is a chain of dependent memory round trips otherwise, and at small batch
+// it sits on the critical path of every layer.
 template <int CODE, int D>
 __global__ void decode_reduce_kernel(const float* __restrict__ part_acc,
                                      const float* __restrict__ part_ml,
                                      uint16_t* __restrict__ out, long o_stride_b,
                                      long o_stride_h, int Hq, int nsplit) {
+    __shared__ float s_f[64];
+    __shared__ float s_l;
     const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const long base = ((long)b * Hq + head) * nsplit;
-    float M = -INFINITY;
-    for (int s = 0; s < nsplit; ++s) M = fmaxf(M, part_ml[(base + s) * 2]);
-    float o = 0.f, l = 0.f;
-    for (int s = 0; s < nsplit; ++s) {
-        const float ms = part_ml[(base + s) * 2];
+    if (d < 64) {                                       // nsplit <= 64 (checked by the launcher)
+        const float ms = d < nsplit ? part_ml[(base + d) * 2] : -INFINITY;
+        const float ls = d < nsplit ? part_ml[(base + d) * 2 + 1] : 0.f;
+        const float M = wave_max(ms);
         const float f = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ms - M);
-        o += part_acc[(base + s) * D + d] * f;
-        l += part_ml[(base + s) * 2 + 1] * f;
+        s_f[d] = f;
+        const float l = wave_sum(ls * f);
+        if (d == 0) s_l = l;
     }
+    __syncthreads();
+    float o = 0.f;
+    int s = 0;
+    for (; s + 8 <= nsplit; s += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = part_acc[(base + s + j) * D + d];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o += v[j] * s_f[s + j];
+    }
+    for (; s < nsplit; ++s) o += part_acc[(base + s) * D + d] * s_f[s];
+    const float l = s_l;
     out[b * o_stride_b + head * o_stride_h + d] = DType<CODE>::from_float(l > 0.f ? o / l : 0.f);
 }
 
@@ -287,7 +304,8 @@ extern "C" int mvl_paged_attention_decode(
         float* part_ml, float scale, int B, int Hq, int Hkv, int D, int block_size, int nsplit,
         int dtype, void* stream) {
     if (B == 0) return 0;
-    if ((D != 64 && D != 128) || Hq % Hkv != 0 || (block_size & (block_size - 1)) || nsplit < 1)
+    if ((D != 64 && D != 128) || Hq % Hkv != 0 || (block_size & (block_size - 1)) || nsplit < 1 ||
+        nsplit > 64)
         return -1;
     if (nsplit > 1 && (part_acc == nullptr || part_ml == nullptr)) return -2;
     auto st = (hipStream_t)stream;

@@ -117,6 +117,8 @@ class ModelRunner:
             load_weights_from_checkpoint(self.model, cfg.checkpoint_path)
         else:
             self.model.init_random_weights(cfg.seed)
+        if self.on_gpu and cfg.fold_norm_weights:
+            self.model.fold_norm_weights()
         self.sampler = SamplerLayer(seed=cfg.seed)
         self.step_counter = 0
         self._decode_prev = None          # (batch list object, arrays) of the last decode step

@@ -21,6 +21,21 @@ class RMSNorm(nn.Module):
         super().__init__()
         self.eps = eps
         self.weight = nn.Parameter(torch.ones(hidden_size), requires_grad=False)
+        # True once the scale vector has been multiplied into the weights of the projection
+        # that consumes this norm's output (``weight`` is all ones from then on)
+        self.folded = False
+
+    @torch.no_grad()
+    def fold_into(self, *linear_weights: torch.Tensor) -> None:
+        """``norm(x) * g @ W.T == norm(x) @ (W * g).T``: move the scale vector into ``W`` (shape
+        [out, in]) so that the normalisation left in front of the GEMM is a per-row scalar."""
+        if self.folded:
+            return
+        g = self.weight.float()
+        for w in linear_weights:
+            w.copy_((w.float() * g[None, :]).to(w.dtype))
+        self.weight.fill_(1.0)
+        self.folded = True
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:

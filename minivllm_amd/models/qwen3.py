@@ -61,8 +61,12 @@ class Qwen3Attention(nn.Module):
         self.attn = Attention(self.num_heads, head_dim, scale, self.num_kv_heads)
 
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor) -> torch.Tensor:
+        return self.attend(positions, self.qkv_proj(hidden))
+
+    def attend(self, positions: torch.Tensor, qkv: torch.Tensor) -> torch.Tensor:
+        """Everything after the QKV projection (the decoder layer may have produced ``qkv``
+        together with the preceding norm in one kernel)."""
         ctx = get_context()
-        qkv = self.qkv_proj(hidden)
         q, k, v = ops.qk_norm_rope_store(
             qkv, positions, self._rope[0].cos_sin_cache,
             self.q_norm.weight if self.use_qk_norm else None,
@@ -95,15 +99,21 @@ class Qwen3DecoderLayer(nn.Module):
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_epsilon)
 
     def forward(self, positions, hidden, residual):
-        if residual is None:
-            residual = hidden
-            hidden = self.input_layernorm(hidden)
-        else:
-            hidden, residual = self.input_layernorm(hidden, residual)
-        hidden = self.self_attn(positions, hidden)
-        hidden, residual = self.post_attention_layernorm(hidden, residual)
-        hidden = self.mlp(hidden)
-        return hidden, residual
+        # Each norm is handed to ops together with the projection that consumes its output:
+        # for decode batches of a few rows the pair runs as one weight-streaming kernel,
+        # otherwise as the (fused add +) norm kernel followed by the GEMM.
+        n1, n2 = self.input_layernorm, self.post_attention_layernorm
+        qkv_proj, gate_up = self.self_attn.qkv_proj, self.mlp.gate_up_proj
+        qkv, residual = ops.norm_linear(hidden, residual, n1.weight, n1.eps, qkv_proj.weight,
+                                        qkv_proj.bias, gamma_folded=n1.folded)
+        hidden = self.self_attn.attend(positions, qkv)
+        act, residual = ops.norm_linear(hidden, residual, n2.weight, n2.eps, gate_up.weight,
+                                        gate_up.bias, swiglu=True, gamma_folded=n2.folded)
+        return self.mlp.down_proj(act), residual
+
+    def fold_norm_weights(self) -> None:
+        self.input_layernorm.fold_into(self.self_attn.qkv_proj.weight)
+        self.post_attention_layernorm.fold_into(self.mlp.gate_up_proj.weight)
 
 
 class Qwen3Model(nn.Module):
@@ -168,6 +178,15 @@ class Qwen3ForCausalLM(nn.Module):
         return self.lm_head.local_logits(hidden)
 
     @torch.no_grad()
+    def fold_norm_weights(self) -> None:
+        """Multiply the scale vectors of the two per-layer norms into the QKV and gate_up
+        weights (call once, after the weights are in place).  The math is unchanged; what it
+        buys is that (residual add + norm + projection) can run as one kernel for decode-sized
+        batches.  The final norm stays as it is: its consumer, the LM head, may be tied to the
+        embedding table."""
+        for layer in self.model.layers:
+            layer.fold_norm_weights()
+
     def init_random_weights(self, seed: int = 0, std: float = 0.02) -> None:
         """Deterministic random init that is identical for every TP degree: each full
         tensor is drawn from its own seeded CPU generator and sharded through the same

@@ -89,6 +89,28 @@ def swiglu_linear(x, weight, bias=None):
     return silu_and_mul(F.linear(x, weight, bias))
 
 
+def fuses_norm_linear(x, weight, swiglu=False) -> bool:
+    """True when ``norm_linear`` runs as one kernel for these operands (decode batches of one
+    or two rows on the GPU), provided the weight carries the norm's scale vector."""
+    return (_on_gpu(x) and x.dim() == 2 and x.shape[0] <= 2
+            and _hip().skinny_norm_gemm_pays(x, weight, swiglu))
+
+
+def norm_linear(x, residual, gamma, eps, weight, bias=None, swiglu=False, gamma_folded=False):
+    """``r = x + residual`` (or ``x``); returns ``(proj(rms_norm(r) * gamma), r)`` where proj is
+    ``linear`` or, with ``swiglu``, ``swiglu_linear``.  ``gamma_folded`` says that ``weight``
+    was multiplied by ``gamma`` along its input dimension at load time (``gamma`` itself is all
+    ones then); only such weights can take the one-kernel path, every other case runs the norm
+    kernel followed by the projection."""
+    if gamma_folded and fuses_norm_linear(x, weight, swiglu):
+        return _hip().skinny_norm_linear(x, residual, eps, weight, bias, swiglu)
+    if residual is None:
+        residual, h = x, rms_norm(x, gamma, eps)
+    else:
+        h, residual = add_rms_norm(x, residual, gamma, eps)
+    return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), residual
+
+
 def sample(logits, temperatures, seed=0, step=0, generator=None):
     """Returns int64 token ids [B]."""
     if _on_gpu(logits):

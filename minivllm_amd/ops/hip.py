@@ -45,7 +45,7 @@ _rope = _sig("mvl_qk_norm_rope_store", _c_void, _c_long, _c_void, _c_void, _c_vo
 _store = _sig("mvl_store_kvcache", _c_void, _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
               _c_long, _c_long, _c_int, _c_void, _c_long, _c_int, _c_int, _c_void)
 _sample = _sig("mvl_sample", _c_void, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void, _c_u64,
-               _c_void, _c_void, _c_void, _c_int, _c_void)
+               _c_void, _c_void, _c_void, _c_int, _c_int, _c_void, _c_void, _c_void)
 _decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
                _c_long, _c_long, _c_void, _c_int, _c_void, _c_void, _c_long, _c_long, _c_void,
                _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void)
@@ -60,6 +60,10 @@ _naive = _sig("mvl_naive_attention", _c_void, _c_long, _c_long, _c_void, _c_void
 
 _skinny = _sig("mvl_skinny_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_int,
                _c_int, _c_int, _c_int, _c_int, _c_void)
+
+_skinny_norm = _sig("mvl_skinny_norm_gemm", _c_void, _c_long, _c_void, _c_long, _c_void, _c_long,
+                    _c_float, _c_void, _c_void, _c_void, _c_long, _c_int, _c_int, _c_int,
+                    _c_int, _c_int, _c_void)
 
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 
@@ -333,12 +337,48 @@ def skinny_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Te
     return out
 
 
+SKINNY_NORM_MAX_ROWS = 2          # beyond this the two-kernel path is faster (measured)
+
+
+def skinny_norm_gemm_pays(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
+    """Shapes for which (residual add + RMSNorm + projection) runs as ONE weight-streaming
+    kernel: 1-2 rows and a projection the plain weight-streaming kernel takes (also QKV-sized
+    outputs, where dropping the norm launch outweighs the library's small GEMM advantage)."""
+    if x.dim() != 2 or x.shape[0] > SKINNY_NORM_MAX_ROWS or not skinny_gemm_ok(x, weight, swiglu):
+        return False
+    return swiglu or weight.shape[0] <= 8192
+
+
+def skinny_norm_linear(x: torch.Tensor, residual: Optional[torch.Tensor], eps: float,
+                       weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+                       swiglu: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """``r = x + residual`` (``x`` when residual is None); returns
+    ``(linear_or_swiglu(r * rsqrt(mean(r^2) + eps)), r)`` for a ``weight`` that already carries
+    the norm's scale vector.  ``r`` is a new tensor: the inputs are left untouched (other
+    workgroups of the kernel are still reading them)."""
+    M, K = x.shape
+    N = weight.shape[0]
+    out = torch.empty((M, N // 2 if swiglu else N), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        assert residual.shape == x.shape and residual.stride(1) == 1
+        r = torch.empty((M, K), dtype=x.dtype, device=x.device)
+        rin, rin_s, rout, rout_s = residual.data_ptr(), residual.stride(0), r.data_ptr(), K
+    else:
+        r, rin, rin_s, rout, rout_s = x, None, 0, None, 0
+    _check(_skinny_norm(x.data_ptr(), x.stride(0), rin, rin_s, rout, rout_s, eps,
+                        weight.data_ptr(), bias.data_ptr() if bias is not None else None,
+                        out.data_ptr(), out.stride(0), M, N, K, 1 if swiglu else 0, _dt(x),
+                        _stream()), "skinny_norm_gemm")
+    return out, r
+
+
 # -------------------------------------------------------------------- sampler
 _LOGIT_DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
 
 
 def sample_local(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, step,
-                 vocab_offset: int = 0, valid_vocab: Optional[int] = None):
+                 vocab_offset: int = 0, valid_vocab: Optional[int] = None,
+                 chunks: Optional[int] = None):
     """Best (score, global index) per row over this rank's vocabulary shard.
     ``step`` is an int or a 1-element int32 device tensor (graph-safe)."""
     assert logits.dim() == 2 and logits.stride(1) == 1
@@ -350,9 +390,18 @@ def sample_local(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, st
     temps = temperatures if temperatures.dtype == torch.float32 else temperatures.float()
     vals = torch.empty(B, dtype=torch.float32, device=logits.device)
     idx = torch.empty(B, dtype=torch.int32, device=logits.device)
+    # few rows: split each over several workgroups so that the whole chip takes part
+    if chunks is None:
+        chunks = max(1, min(16, 256 // max(B, 1))) if V >= 16384 else 1
+    if chunks > 1:
+        ws_val = torch.empty(B * chunks, dtype=torch.float32, device=logits.device)
+        ws_idx = torch.empty(B * chunks, dtype=torch.int32, device=logits.device)
+        wv, wi = ws_val.data_ptr(), ws_idx.data_ptr()
+    else:
+        wv = wi = None
     _check(_sample(logits.data_ptr(), logits.stride(0), B, V, vocab_offset, valid_vocab,
                    temps.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF, step.data_ptr(), vals.data_ptr(),
-                   idx.data_ptr(), _LOGIT_DT[logits.dtype], _stream()), "sample")
+                   idx.data_ptr(), _LOGIT_DT[logits.dtype], chunks, wv, wi, _stream()), "sample")
     return vals, idx
 
 

@@ -158,6 +158,23 @@ def test_sampler_vocab_shards_agree(hip):
     assert torch.equal(idx.gather(0, best[None]).squeeze(0), full_i)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("V", [151936, 16390, 40000])
+def test_sampler_split_rows_equal_single_workgroup_rows(hip, dtype, V):
+    """Small batches split every row over several workgroups and merge the partial winners:
+    same scores, same tokens as one workgroup per row (noise is keyed by vocabulary index)."""
+    torch.manual_seed(8)
+    logits = torch.randn(3, V + 6, device=DEV, dtype=dtype)[:, :V]        # row stride != V
+    temps = torch.tensor([0.0, 0.7, 1.3], device=DEV)
+    one_v, one_i = hip.sample_local(logits, temps, 5, 11, valid_vocab=V - 3, chunks=1)
+    for chunks in (2, 7, 16):
+        v, i = hip.sample_local(logits, temps, 5, 11, valid_vocab=V - 3, chunks=chunks)
+        assert torch.equal(i, one_i) and torch.equal(v, one_v)
+    auto_v, auto_i = hip.sample_local(logits, temps, 5, 11, valid_vocab=V - 3)
+    assert torch.equal(auto_i, one_i)
+    assert one_i[0].item() == logits[0, :V - 3].float().argmax().item()
+
+
 # ------------------------------------------------------------------- attention
 def _fill_paged(k, v, lens, bs, hkv, d, dtype, head_major=True, shuffle=True):
     """Scatter packed k/v [sum(lens), hkv, d] into a paged cache; returns caches + tables."""
@@ -331,6 +348,30 @@ def test_skinny_gemm(hip, dtype, M, N, K):
     want = x.float() @ w.float().T
     close(hip.skinny_linear(x, w), want, dtype, 4)
     close(hip.skinny_linear(x, w, b), want + b.float(), dtype, 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,K,N,swiglu,with_res", [
+    (1, 4096, 6144, False, True), (8, 4096, 6144, False, True), (3, 4096, 24576, True, True),
+    (8, 4096, 24576, True, True), (2, 5120, 7168, False, False), (5, 2048, 8192, True, True)])
+def test_skinny_norm_gemm(hip, dtype, M, K, N, swiglu, with_res):
+    """residual add + RMSNorm + projection in one kernel (weights carry the norm's scale
+    vector) vs the fp32 formula; the new residual must be the rounded sum, bit for bit."""
+    torch.manual_seed(23)
+    xx = torch.randn(M + 2, K + 32, device=DEV, dtype=dtype)
+    x = xx[:M, :K]                                              # strided rows
+    res = torch.randn(M, K, device=DEV, dtype=dtype) if with_res else None
+    w = (torch.randn(N, K, device=DEV) * 0.03).to(dtype)
+    x0, res0 = x.clone(), (res.clone() if with_res else None)
+    assert hip.skinny_norm_gemm_pays(x, w, swiglu) == (M <= hip.SKINNY_NORM_MAX_ROWS)
+    out, r = hip.skinny_norm_linear(x, res, 1e-6, w, swiglu=swiglu)
+    r_want = (x0.float() + res0.float()).to(dtype) if with_res else x0
+    assert torch.equal(r, r_want)
+    assert torch.equal(x, x0) and (not with_res or torch.equal(res, res0))    # inputs untouched
+    rf = r_want.float()
+    y = (rf @ w.float().T) * torch.rsqrt(rf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    want = torch.nn.functional.silu(y[:, :N // 2]) * y[:, N // 2:] if swiglu else y
+    close(out, want, dtype, 4)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
