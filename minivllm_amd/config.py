@@ -140,6 +140,9 @@ class EngineConfig:
     # let a prompt longer than the step's token budget be prefetched over several steps (the
     # reference can never schedule such a prompt)
     enable_chunked_prefill: bool = True
+    # > 0: while sequences are decoding, start a prefill step only when at least this many prompt
+    # tokens can be admitted at once (0 = the reference policy: every newcomer interrupts decode)
+    min_prefill_tokens: int = 0
     # all-reduce decode-sized tensors with the peer-to-peer kernel (parallel/custom_allreduce.py)
     # instead of RCCL; larger tensors still go to RCCL.  Also switched on by MINIVLLM_CUSTOM_AR=1.
     custom_all_reduce: bool = False

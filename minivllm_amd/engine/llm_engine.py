@@ -80,7 +80,8 @@ class LLMEngine:
         self.scheduler = Scheduler(cfg.max_num_sequences, cfg.max_num_batched_tokens,
                                    self.model_runner.num_kv_blocks, cfg.block_size, cfg.eos,
                                    max_model_length=cfg.max_model_length,
-                                   enable_chunked_prefill=cfg.enable_chunked_prefill)
+                                   enable_chunked_prefill=cfg.enable_chunked_prefill,
+                                   min_prefill_tokens=cfg.min_prefill_tokens)
         self.tokenizer = load_tokenizer(cfg.model_name_or_path, cfg.model.vocab_size)
         self.stats = EngineStats()
         self._exited = False

@@ -29,8 +29,14 @@ from .sequence import Sequence, SequenceStatus
 class Scheduler:
     def __init__(self, max_num_sequences: int, max_num_batched_tokens: int,
                  max_cached_blocks: int, block_size: int, eos: int,
-                 max_model_length: Optional[int] = None, enable_chunked_prefill: bool = True):
+                 max_model_length: Optional[int] = None, enable_chunked_prefill: bool = True,
+                 min_prefill_tokens: int = 0):
         self.enable_chunked_prefill = enable_chunked_prefill
+        # > 0: while sequences are decoding, newcomers are admitted only once this many prompt
+        # tokens can go into one prefill step (or everything that waits fits).  The reference
+        # interrupts the decode batch for every single newcomer (scheduler.py:29-41), which
+        # turns a saturated server into an alternation of full decode steps and tiny prefills.
+        self.min_prefill_tokens = min_prefill_tokens
         # admitted (blocks allocated) but not yet completely prefetched, oldest first
         self.prefilling: Deque[Sequence] = deque()
         self.block_manager = make_block_manager(max_cached_blocks, block_size)
@@ -95,6 +101,8 @@ class Scheduler:
         # while an older sequence is still incomplete after this step: a newcomer could hit its
         # prefix-cache blocks before their KV exists.
         while (self.waiting and not self.prefilling and len(scheduled) < self.max_num_sequences):
+            if not scheduled and self._defer_prefill():
+                break
             seq = self.waiting[0]
             fits = num_tokens + len(seq) <= budget
             # a cut sequence gets at least one KV block worth of tokens now, or waits
@@ -167,6 +175,19 @@ class Scheduler:
         else:
             self._decode_batch = None
         return scheduled, False
+
+    def _defer_prefill(self) -> bool:
+        """Keep decoding instead of starting a prefill step that would carry too few tokens."""
+        if not self.min_prefill_tokens or not self.running:
+            return False
+        slots = self.max_num_sequences - len(self.running)
+        tokens = admitted = 0
+        for seq in self.waiting:
+            if admitted >= slots or tokens >= self.min_prefill_tokens:
+                break
+            tokens += len(seq)
+            admitted += 1
+        return tokens < self.min_prefill_tokens and admitted < len(self.waiting)
 
     def preempt(self, seq: Sequence) -> None:
         self._decode_batch = None

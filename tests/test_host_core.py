@@ -300,3 +300,30 @@ def test_preempting_drops_chunk_state():
     sch.prefilling.clear()
     sch.preempt(a)
     assert a.prefill_end is None and a.num_cached_tokens == 0 and a.block_table == []
+
+
+def test_prefill_is_deferred_until_enough_tokens_can_be_admitted():
+    sch = Scheduler(4, 64, 64, BS, 999, min_prefill_tokens=10)
+    first = [seq(range(i * 10, i * 10 + 6), max_tokens=3) for i in range(4)]
+    for s in first:
+        sch.add_sequence(s)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == first                       # nothing is running: no deferral
+    sch.postprocess(batch, [1] * 4)
+    late = [seq(range(100 + i * 10, 106 + i * 10), max_tokens=2) for i in range(3)]
+    for s in late:
+        sch.add_sequence(s)
+    first[0].max_tokens = 2                                    # will finish after this step
+    batch, is_prefill = sch.schedule()
+    assert not is_prefill                                      # no free slot anyway
+    sch.postprocess(batch, [2] * 4)                            # first[0] finishes -> 1 slot
+    batch, is_prefill = sch.schedule()
+    assert not is_prefill and len(batch) == 3                  # 6 tokens < 10: keep decoding
+    sch.postprocess(batch, [3] * 3)                            # all three finish (max_tokens 3)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == late                        # nothing running any more
+    one = seq(range(7))
+    sch.postprocess(batch, [4] * 3)
+    sch.add_sequence(one)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == [one]                       # everything that waits fits
