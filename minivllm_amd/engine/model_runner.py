@@ -61,6 +61,16 @@ class Batch:
                     step=self.step, tables_unchanged=self.tables_unchanged)
 
 
+def prefill_token_bucket(num_tokens: int) -> int:
+    """Token count a prefill step is padded to.  The GEMM library chooses (and PyTorch caches)
+    a kernel per problem shape, and an unseen shape costs milliseconds of host time on its
+    first use; with arbitrary token counts nearly every prefill step of a busy server brings
+    four new shapes and small steps end up bound by the host.  Rounding up to a few dozen
+    distinct sizes (at most ~6 % extra rows) makes the shapes repeat."""
+    g = 64 if num_tokens <= 1024 else 256 if num_tokens <= 4096 else 512
+    return (num_tokens + g - 1) // g * g
+
+
 def default_graph_batch_sizes(max_bs: int) -> List[int]:
     """Same bucket policy as the reference: 1,2,4,8 then multiples of 16
     (reference: model_runner.py:334)."""
@@ -349,10 +359,19 @@ class ModelRunner:
         for i, s in enumerate(seqs):
             tables[i, :len(s.block_table)] = s.block_table
         input_ids = np.concatenate(ids)
+        positions = np.concatenate(pos)
+        slot_mapping = np.concatenate(slots).astype(np.int32)
+        pad = prefill_token_bucket(input_ids.size) - input_ids.size if self.on_gpu else 0
+        if pad:
+            # rows that belong to no sequence: attention and the LM head go by cu_seqlens and
+            # never see them, the KV store skips slot -1, every other op is row-wise
+            input_ids = np.concatenate([input_ids, np.zeros(pad, np.int32)])
+            positions = np.concatenate([positions, np.zeros(pad, np.int32)])
+            slot_mapping = np.concatenate([slot_mapping, np.full(pad, -1, np.int32)])
         return Batch(is_prefill=True, num_seqs=B, num_tokens=int(input_ids.size),
                      max_seqlen_q=max_q, max_seqlen_k=max_k, has_prefix=has_prefix,
-                     arrays=dict(input_ids=input_ids, positions=np.concatenate(pos),
-                                 slot_mapping=np.concatenate(slots).astype(np.int32),
+                     arrays=dict(input_ids=input_ids, positions=positions,
+                                 slot_mapping=slot_mapping,
                                  cu_seqlens_q=np.asarray(cu_q, np.int32),
                                  cu_seqlens_k=np.asarray(cu_k, np.int32),
                                  temperatures=np.asarray([s.temperature for s in seqs], np.float32),
