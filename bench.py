@@ -256,6 +256,69 @@ def published_reference_check():
         return {"error": repr(e)}
 
 
+def phase_ok(r) -> bool:
+    return bool(r is not None and "error" not in r and r.get("main"))
+
+
+def headline(m):
+    return (round(m.get("decode_tok_s", m.get("prefill_tok_s")), 1),
+            round(m.get("decode_ms_per_step", m.get("prefill_ms_per_step")), 3))
+
+
+def assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common):
+    """The one JSON object of an N > 1 run from the phase results (each a dict from
+    ``spawn_phase``, ``{'error': ...}`` or None when the phase was skipped).  Returns
+    (object, whether any phase delivered a number).  Headline = data parallel; if that phase
+    failed, tensor parallel; if both failed, value 0 with the errors."""
+    B = args.batch
+
+    def scaled(m):                               # per-replica numbers -> whole job
+        d = dict(m)
+        for k in ("decode_tok_s", "prefill_tok_s", "prefill_tokens_per_step"):
+            if k in d:
+                d[k] = d[k] * world
+        return d
+
+    def tp_section(r):
+        if not phase_ok(r):
+            return r
+        sec = {"parallelism": f"tp{world}", "scaling": "strong", "global_batch": B,
+               **_round(r["main"]), "phase_wall_s": r.get("phase_wall_s")}
+        if r.get("second"):
+            sec["secondary"] = {"model": args.second_model, **_round(r["second"])}
+        return sec
+
+    if phase_ok(dp):
+        m = scaled(dp["main"])
+        value, ms = headline(m)
+        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "weak",
+               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "replica": "tp1, one engine per GPU"},
+               **_round(m), "phase_wall_s": dp.get("phase_wall_s"),
+               "published_reference_check": dp.get("published_reference_check")}
+        if dp.get("second"):
+            out["secondary"] = {"model": args.second_model, **_round(scaled(dp["second"]))}
+        if tp is not None:
+            out["tensor_parallel"] = tp_section(tp)
+        if tpc is not None:
+            out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
+    elif phase_ok(tp):
+        value, ms = headline(tp["main"])
+        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "strong",
+               "config": {**cfg_common, "global_batch": B, "parallelism": f"tp{world}"},
+               **_round(tp["main"]), "data_parallel_replicas": dp}
+        if tp.get("second"):
+            out["secondary"] = {"model": args.second_model, **_round(tp["second"])}
+        if tpc is not None:
+            out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
+    else:
+        out = {"metric": metric, "value": 0.0, **base, "ms_per_step": None, "scaling": "weak",
+               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}"},
+               "data_parallel_replicas": dp, "tensor_parallel": tp,
+               "tensor_parallel_p2p_allreduce": tpc}
+    return out, phase_ok(dp) or phase_ok(tp)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -310,10 +373,6 @@ def main():
                   **({"layers_override": args.layers} if args.layers else {})}
     metric = f"decode tok/s ({args.model}, engine step); prefill tok/s in prefill_tok_s"
 
-    def headline(m):
-        return (round(m.get("decode_tok_s", m.get("prefill_tok_s")), 1),
-                round(m.get("decode_ms_per_step", m.get("prefill_ms_per_step")), 3))
-
     if world == 1:
         res = run_phase(args, "single", rank, local_rank, world)
         m, second = res["main"], res["second"]
@@ -333,56 +392,9 @@ def main():
            else spawn_phase(args, "tpc", rank, local_rank, world))
     if rank != 0:
         return
-
-    def ok(r):
-        return r is not None and "error" not in r and r.get("main")
-
-    def scaled(m):                               # per-replica numbers -> whole job
-        d = dict(m)
-        for k in ("decode_tok_s", "prefill_tok_s", "prefill_tokens_per_step"):
-            if k in d:
-                d[k] = d[k] * world
-        return d
-
-    def tp_section(r):
-        if not ok(r):
-            return r
-        sec = {"parallelism": f"tp{world}", "scaling": "strong", "global_batch": B,
-               **_round(r["main"]), "phase_wall_s": r.get("phase_wall_s")}
-        if r.get("second"):
-            sec["secondary"] = {"model": args.second_model, **_round(r["second"])}
-        return sec
-
-    if ok(dp):
-        m = scaled(dp["main"])
-        value, ms = headline(m)
-        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "weak",
-               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}",
-                          "replica": "tp1, one engine per GPU"},
-               **_round(m), "phase_wall_s": dp.get("phase_wall_s"),
-               "published_reference_check": dp.get("published_reference_check")}
-        if dp.get("second"):
-            out["secondary"] = {"model": args.second_model, **_round(scaled(dp["second"]))}
-        if tp is not None:
-            out["tensor_parallel"] = tp_section(tp)
-        if tpc is not None:
-            out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
-    elif ok(tp):
-        value, ms = headline(tp["main"])
-        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "strong",
-               "config": {**cfg_common, "global_batch": B, "parallelism": f"tp{world}"},
-               **_round(tp["main"]), "data_parallel_replicas": dp}
-        if tp.get("second"):
-            out["secondary"] = {"model": args.second_model, **_round(tp["second"])}
-        if tpc is not None:
-            out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
-    else:
-        out = {"metric": metric, "value": 0.0, **base, "ms_per_step": None, "scaling": "weak",
-               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}"},
-               "data_parallel_replicas": dp, "tensor_parallel": tp,
-               "tensor_parallel_p2p_allreduce": tpc}
+    out, good = assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common)
     print(json.dumps(out), flush=True)
-    if not (ok(dp) or ok(tp)):
+    if not good:
         sys.exit(1)
 
 
