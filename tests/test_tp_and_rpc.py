@@ -144,6 +144,28 @@ def test_tp2_gloo_matches_tp1():
     assert not pg.is_initialized()                  # exit() tore the group down
 
 
+def test_tp4_gloo_matches_tp1():
+    """Four ranks: every head count, the vocabulary padding (331 -> multiple of 256) and the
+    four-way (value, index) sampling exchange differ from the two-rank case."""
+    import dataclasses
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    port = 29000 + os.getpid() % 250
+
+    def run(world, p):
+        base = _cfg(world, p)
+        cfg = dataclasses.replace(base, model=dataclasses.replace(base.model, num_kv_heads=4,
+                                                                  intermediate_size=128))
+        eng = LLMEngine(cfg)
+        rng = np.random.default_rng(4)
+        prompts = [rng.integers(0, 331, size=n).tolist() for n in (7, 19, 3, 26)]
+        out = eng.generate(prompts, SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+        eng.exit()
+        return out["token_ids"]
+
+    assert run(4, port + 4) == run(1, port)
+    assert not pg.is_initialized()
+
+
 def test_forced_single_rank_group_runs_the_sharded_path():
     """world_size 1 with force_tp_group: collectives go through a real (gloo) group."""
     import dataclasses
