@@ -187,7 +187,7 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
     os.environ["MINIVLLM_KEEP_PG"] = "1"         # two engines in a row share one process group
     models = [args.model] + ([args.second_model] if args.second_model
                              and args.second_model != args.model and phase != "tpc" else [])
-    if phase == "dp" and world > 1:
+    if phase == "dp" and (world > 1 or os.environ.get("MINIVLLM_FORCE_PG") == "1"):
         import torch.distributed as dist
         backend = os.environ.get("MINIVLLM_DIST_BACKEND", "nccl")
         kw = ({"device_id": torch.device("cuda", torch.cuda.current_device())}
@@ -197,6 +197,12 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
                                 rank=rank, world_size=world, **kw)
     out = [bench_model(args, m, rank, world, replicas=(phase not in ("tp", "tpc")))
            for m in models]
+    import torch.distributed as dist
+    if dist.is_initialized():                    # kept alive across the engines of this phase
+        try:
+            dist.destroy_process_group()
+        except Exception:
+            pass
     if rank != 0:
         return None
     return {"main": out[0], "second": out[1] if len(out) > 1 else None}
