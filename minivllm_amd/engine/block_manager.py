@@ -287,12 +287,16 @@ class NativeBlockManager:
         seq.num_cached_tokens = 0
 
     def can_append(self, seq: Sequence) -> bool:
-        need_new = len(seq.block_table) < seq.num_blocks
-        return self.num_free_blocks >= int(need_new)
+        # the common decode step neither starts nor completes a block: no call into the library
+        if len(seq.block_table) >= seq.num_blocks:
+            return True
+        return self.num_free_blocks >= 1
 
     def append(self, seq: Sequence) -> None:
         n = seq.num_tokens
         bt = seq.block_table
+        if n % self.block_size != 0 and len(bt) >= seq.num_blocks:
+            return                                        # nothing to allocate, nothing to publish
         last_tokens = None
         if n % self.block_size == 0:                      # this step fills the last block
             last_tokens = np.ascontiguousarray(seq.block(seq.num_blocks - 1), dtype=np.int32)

@@ -25,6 +25,7 @@ from __future__ import annotations
 import os
 import time
 from dataclasses import dataclass, field
+from itertools import chain
 from typing import Dict, List, Optional, Sequence as Seq
 
 import numpy as np
@@ -59,6 +60,16 @@ class Batch:
                     max_seqlen_q=self.max_seqlen_q, max_seqlen_k=self.max_seqlen_k,
                     max_context_len=self.max_context_len, has_prefix=self.has_prefix,
                     step=self.step, tables_unchanged=self.tables_unchanged)
+
+
+def _pad_block_tables(tables: List[List[int]]) -> np.ndarray:
+    """[B, max blocks] int32, rows padded with -1, without a Python-level loop over rows."""
+    n = np.fromiter(map(len, tables), np.int64, len(tables))
+    flat = np.fromiter(chain.from_iterable(tables), np.int32, int(n.sum()))
+    out = np.full((len(tables), int(n.max())), -1, np.int32)
+    starts = np.cumsum(n) - n
+    out[np.repeat(np.arange(len(tables)), n), np.arange(flat.size) - np.repeat(starts, n)] = flat
+    return out
 
 
 def prefill_token_bucket(num_tokens: int) -> int:
@@ -398,11 +409,8 @@ class ModelRunner:
             return Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1, max_seqlen_k=m,
                          max_context_len=m, arrays=arrays, tables_unchanged=True)
         lens = np.fromiter((s.num_tokens for s in seqs), np.int32, B)
-        last_block = np.fromiter((s.block_table[-1] for s in seqs), np.int32, B)
-        MB = max(len(s.block_table) for s in seqs)
-        tables = np.full((B, MB), -1, np.int32)
-        for i, s in enumerate(seqs):
-            tables[i, :len(s.block_table)] = s.block_table
+        tables = _pad_block_tables([s.block_table for s in seqs])
+        last_block = tables[self._arange(B), (lens - 1) // bs]
         pos = lens - 1
         arrays = dict(input_ids=np.fromiter((s.last_token for s in seqs), np.int32, B),
                       positions=pos, slot_mapping=last_block * bs + pos % bs, context_lens=lens,

@@ -140,31 +140,35 @@ class Scheduler:
             return self._decode_batch, False
         candidates = self.running
         self.running = deque()
+        bs = self.block_size
         deferred: List[Sequence] = []
         while candidates:
             seq = candidates.popleft()
             if len(scheduled) >= self.max_num_sequences or num_tokens >= self.max_num_batched_tokens:
                 deferred.append(seq)
                 continue
-            preempted_self = False
-            while not bm.can_append(seq):
-                if candidates:
-                    self.preempt(candidates.pop())      # newest sequence is the victim
-                elif deferred:
-                    self.preempt(deferred.pop())
-                else:
-                    self.preempt(seq)
-                    preempted_self = True
-                    break
-            if preempted_self:
-                continue
-            bm.append(seq)
+            n = seq.num_tokens
+            if len(seq.block_table) * bs < n:           # this token starts a new KV block
+                preempted_self = False
+                while not bm.can_append(seq):
+                    if candidates:
+                        self.preempt(candidates.pop())  # newest sequence is the victim
+                    elif deferred:
+                        self.preempt(deferred.pop())
+                    else:
+                        self.preempt(seq)
+                        preempted_self = True
+                        break
+                if preempted_self:
+                    continue
+                bm.append(seq)
+            elif n % bs == 0:                           # this token completes a block: publish it
+                bm.append(seq)
             scheduled.append(seq)
             num_tokens += 1
         self.running.extend(scheduled)
         self.running.extend(deferred)
         if scheduled and not deferred and not self.waiting:
-            bs = self.block_size
             # after this step a sequence holds n + 1 tokens; the step scheduled for length m
             # is plain unless m % bs is 0 (publishes a hash) or 1 (needs a new block)
             plain = bs
