@@ -31,6 +31,7 @@ echo "== attention micro-benchmarks (1 GPU)"
 python benchmark_prefilling.py --json "$OUT/benchmark_prefilling.json" > "$OUT/benchmark_prefilling.log" 2>&1
 python benchmark_decoding.py   --json "$OUT/benchmark_decoding.json"   > "$OUT/benchmark_decoding.log" 2>&1
 python benchmark_activation.py --json "$OUT/benchmark_activation.json" > "$OUT/benchmark_activation.log" 2>&1
+python benchmark_throughput.py --json "$OUT/benchmark_throughput.json" > "$OUT/benchmark_throughput.log" 2>&1
 python benchmark_models.py --config qwen3-8b --mode all --quick --json "$OUT/benchmark_models.json" \
   > "$OUT/benchmark_models.log" 2>&1
 echo "== end-to-end demo"
