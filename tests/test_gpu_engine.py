@@ -185,3 +185,22 @@ def test_chunked_prefill_on_gpu_matches_whole_prefill(gpu):
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
     assert same / total > 0.9, (same, total)
+
+
+def test_fp16_engine_generates_like_its_cpu_oracle(gpu):
+    """The whole engine in float16 (the precision the reference's kernel benchmarks use):
+    greedy tokens agree with an fp32 CPU engine that carries the same weights."""
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    prompts = _prompts(4, lo=20, hi=120, seed=11)
+    sp = SamplingParams(temperature=0, max_tokens=12, ignore_eos=True)
+    g = LLMEngine(_cfg(dtype=torch.float16, enforce_eager=False, graph_batch_sizes=[4]))
+    state = {k: v.float().cpu() for k, v in g.model_runner.model.state_dict().items()}
+    got = g.generate(prompts, sp)["token_ids"]
+    g.exit()
+    c = LLMEngine(_cfg(device="cpu", dtype=torch.float32))
+    c.model_runner.model.load_state_dict(state)
+    want = c.generate(prompts, sp)["token_ids"]
+    c.exit()
+    same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
+    total = sum(len(x) for x in want)
+    assert same / total > 0.85, (same, total)
