@@ -131,6 +131,9 @@ class EngineConfig:
     # first GPU of this engine's tensor-parallel group when LOCAL_RANK is not set by a launcher
     # (data-parallel replicas started from one process each take their own range of devices)
     device_base: int = 0
+    # GPU only: at start-up, time the hand-written weight-streaming GEMM against the library on
+    # this model's own projections (1-16 rows) and use whichever is faster per shape
+    tune_decode_gemms: bool = True
     # GPU only, experimental: multiply each layer norm's scale vector into the weights of the
     # projection behind it at load time, which lets 1-2 row decode batches run (residual add +
     # norm + projection) as one kernel (csrc/skinny_norm_gemm.hip).  Measured on Qwen3-8B: 3.93

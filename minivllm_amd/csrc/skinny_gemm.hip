@@ -18,6 +18,7 @@
 //    x fragment and stores silu(gate) * up, which removes the activation kernel and the
 //    [M, 2I] intermediate.
 #include "common.h"
+#include <type_traits>
 
 using namespace mvl;
 
@@ -49,33 +50,35 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
 #pragma unroll
     for (int b = 0; b < NB; ++b) acc[b] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
+    // k-loop in blocks of U steps: all 2 U (3 U with SwiGLU) loads of a block are issued before
+    // the first MFMA waits for one.  A slice that is not a multiple of 8 steps (K = 5120: 20
+    // steps per wave) finishes with blocks of 4, 2 and 1 steps instead of dependent single steps.
     int k = 0;
-    for (; k + 32 * kUnroll <= kslice; k += 32 * kUnroll) {
-        u32x4_t bw[NB][kUnroll], ax[kUnroll];
+    auto run = [&](auto u_tag) {
+        constexpr int U = decltype(u_tag)::value;
+        for (; k + 32 * U <= kslice; k += 32 * U) {
+            u32x4_t bw[NB][U], ax[U];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            bw[0][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp0 + k + 32 * u));
-            if (NB == 2)
-                bw[NB - 1][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp1 + k + 32 * u));
-            ax[u] = *reinterpret_cast<const u32x4_t*>(xp + k + 32 * u);
+            for (int u = 0; u < U; ++u) {
+                bw[0][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp0 + k + 32 * u));
+                if (NB == 2)
+                    bw[NB - 1][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp1 + k + 32 * u));
+                ax[u] = *reinterpret_cast<const u32x4_t*>(xp + k + 32 * u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const vec8 a = __builtin_bit_cast(vec8, ax[u]);
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+                    acc[b] = DT::mfma16(a, __builtin_bit_cast(vec8, bw[b][u]), acc[b]);
+            }
         }
-        // all loads of the block are issued before the first MFMA waits for one of them
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            const vec8 a = __builtin_bit_cast(vec8, ax[u]);
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-                acc[b] = DT::mfma16(a, __builtin_bit_cast(vec8, bw[b][u]), acc[b]);
-        }
-    }
-    for (; k < kslice; k += 32) {
-        const vec8 a = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(xp + k));
-        acc[0] = DT::mfma16(a, __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(wp0 + k)), acc[0]);
-        if (NB == 2)
-            acc[NB - 1] = DT::mfma16(a, __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(wp1 + k)),
-                                     acc[NB - 1]);
-    }
+    };
+    run(std::integral_constant<int, kUnroll>{});
+    run(std::integral_constant<int, 4>{});
+    run(std::integral_constant<int, 2>{});
+    run(std::integral_constant<int, 1>{});
 
     // split-K reduction across the waves; accumulator layout: col n = lane & 15, row m = 4 q + r
 #pragma unroll

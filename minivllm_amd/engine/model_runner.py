@@ -158,6 +158,8 @@ class ModelRunner:
 
         with torch.inference_mode():
             self.warmup_model()
+            if self.on_gpu and cfg.tune_decode_gemms:
+                self._tune_decode_gemms()
             self.allocate_kv_cache()
             if self.on_gpu and not self.enforce_eager:
                 self._capture_graphs_or_fall_back()
@@ -174,6 +176,25 @@ class ModelRunner:
                 self.channel = ShmBroadcastChannel(name, self.world_size - 1, create=False)
                 if spawn_loop:
                     self.loop()
+
+    def _tune_decode_gemms(self) -> None:
+        """Per projection and row bucket: hand-written weight-streaming kernel or library GEMM,
+        decided by timing both on this model's own weights (before the decode graphs are
+        captured, so the choice is baked into them)."""
+        from minivllm_amd.ops import hip
+        layers = list(self.model.model.layers)[:16]
+        roles = {"qkv": ([l.self_attn.qkv_proj.weight for l in layers], False),
+                 "o": ([l.self_attn.o_proj.weight for l in layers], False),
+                 "gate_up": ([l.mlp.gate_up_proj.weight for l in layers], True),
+                 "down": ([l.mlp.down_proj.weight for l in layers], False)}
+        self.decode_gemm_choices = {}
+        for name, (ws, swiglu) in roles.items():
+            self.decode_gemm_choices[name] = hip.tune_skinny_gemm(ws, swiglu)
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if self.rank == 0 and self.cfg.log_stats:
+            print(f"[runner] decode GEMM choices (rows: library us, kernel us, use kernel): "
+                  f"{self.decode_gemm_choices}", flush=True)
 
     # ================================================================ buffers
     def _init_buffers(self) -> None:

@@ -301,29 +301,97 @@ SKINNY_MIN_WEIGHT_BYTES = 8 << 20     # below this a projection is launch-latenc
 
 
 def skinny_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
-    """Shapes the weight-streaming kernel takes: <= 16 rows, K a multiple of 128, enough
-    16-column tiles to cover the chip, weights big enough to be worth streaming by hand."""
+    """Operands the weight-streaming kernel can take at all: <= 16 rows, K a multiple of 128,
+    output columns a multiple of 16, contiguous weights of the activations' dtype."""
     if x.dim() != 2 or x.shape[0] == 0 or x.shape[0] > SKINNY_MAX_ROWS or x.dtype not in _DT:
         return False
     n, k = weight.shape
     n_out = n // 2 if swiglu else n
     return (weight.dtype == x.dtype and weight.is_contiguous() and x.stride(1) == 1
-            and k % 128 == 0 and n_out % 16 == 0 and n_out // 16 >= 192
-            and n * k * 2 >= SKINNY_MIN_WEIGHT_BYTES)
+            and k % 128 == 0 and n_out % 16 == 0 and n % (32 if swiglu else 16) == 0)
+
+
+# (row bucket, N, K, swiglu) -> use the kernel?  Filled by tune_skinny_gemm on the machine the
+# engine runs on; shapes that were never measured fall back to the rule in skinny_gemm_pays.
+_SKINNY_CHOICE: dict = {}
+_SKINNY_ROW_BUCKETS = (1, 8, 16)
+
+
+def _row_bucket(m: int) -> int:
+    return 1 if m <= 2 else 8 if m <= 8 else 16
 
 
 def skinny_gemm_pays(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
-    """Whether the weight-streaming kernel is the faster choice for this call.  Measured against
-    the library GEMM on MI355X (Qwen3-8B shapes, graph replay, weights streamed cold from HBM,
-    tools/skinny_gemm_bench.py, profiles/r1_skinny_gemm_vs_library.txt), 1 / 8 / 16 rows:
-    fused SwiGLU 35.9 / 39.0 / 42.5 us against 45.5 / 45.8 / 46.1 us for GEMM + activation;
-    o-projection (N = K = 4096) 8.3 / 9.4 / 10.9 us against 15.2 / 15.3 / 15.4 us.  With more
-    output columns or a longer K (QKV, down projection) the library is as fast or faster, so
-    those stay with it."""
+    """Whether the weight-streaming kernel is the faster choice for this call.  Which side wins
+    depends on the shape in ways no simple rule captures (MI355X, weights streamed cold, 1 row:
+    Qwen3-8B o-projection 8.3 vs 15.2 us and gate_up+SwiGLU 35.9 vs 45.5 us for the kernel, but
+    Qwen3-32B gate_up+SwiGLU 124 vs 91 us against it, and its down projection 81 vs 134 us for
+    it again), so the engine measures both on its own weights at start-up (tune_skinny_gemm)
+    and this function looks the answer up.  Unmeasured shapes: the kernel for fused SwiGLU and
+    for N, K <= 4096 when the matrix is large enough to cover the chip, the library otherwise."""
     if x.dim() != 2 or x.shape[0] > SKINNY_PAYS_ROWS or not skinny_gemm_ok(x, weight, swiglu):
         return False
     n, k = weight.shape
+    choice = _SKINNY_CHOICE.get((_row_bucket(x.shape[0]), n, k, swiglu))
+    if choice is not None:
+        return choice
+    n_out = n // 2 if swiglu else n
+    if n_out // 16 < 192 or n * k * 2 < SKINNY_MIN_WEIGHT_BYTES:
+        return False                       # too few tiles to cover the chip / launch-bound anyway
     return swiglu or (n <= 4096 and k <= 4096)
+
+
+def tune_skinny_gemm(weights, swiglu: bool = False, margin: float = 0.97) -> dict:
+    """Time the weight-streaming kernel against the library GEMM (+ activation kernel when
+    ``swiglu``) for one projection and record the winner per row bucket.  ``weights`` are the
+    same-shaped matrices of several layers: cycling through them keeps the reads cold, as in a
+    real decode step.  Each candidate is captured into a hipGraph (no launch gaps in the
+    measurement) and replayed three times; the kernel must win by ``1 - margin``."""
+    import torch.nn.functional as F
+    weights = list(weights)
+    n, k = weights[0].shape
+    dtype, dev = weights[0].dtype, weights[0].device
+    out = {}
+    probe = torch.zeros(1, k, dtype=dtype, device=dev)
+    if not skinny_gemm_ok(probe, weights[0], swiglu) or n * k * 2 < (1 << 20):
+        return out                             # below 1 MB either choice is launch latency
+    # enough distinct matrices per pass that the 256 MB Infinity Cache cannot hold them (small
+    # matrices stay cached in the real step as well: no point in more than a few passes)
+    reps = max(1, min(8, -(-(640 << 20) // (n * k * 2 * len(weights)))))
+
+    def lib(x, w):
+        y = F.linear(x, w)
+        return silu_and_mul(y) if swiglu else y
+
+    def ker(x, w):
+        return skinny_linear(x, w, swiglu=swiglu)
+
+    def graph_ms(fn, x):
+        for w in weights[:2]:
+            fn(x, w)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(reps):
+                for w in weights:
+                    fn(x, w)
+        g.replay()
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(3):
+            g.replay()
+        t1.record()
+        torch.cuda.synchronize()
+        return t0.elapsed_time(t1) / (3 * reps * len(weights))
+
+    for m in _SKINNY_ROW_BUCKETS:
+        x = torch.randn(m, k, dtype=dtype, device=dev)
+        t_lib, t_ker = graph_ms(lib, x), graph_ms(ker, x)
+        use = t_ker < margin * t_lib
+        _SKINNY_CHOICE[(m, n, k, swiglu)] = use
+        out[m] = (round(t_lib * 1e3, 1), round(t_ker * 1e3, 1), use)
+    return out
 
 
 def skinny_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,

@@ -5,7 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from minivllm_amd.ops import hip
 
-shapes = {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (24576, 4096), "down": (4096, 12288)}
+SHAPES = {
+    "qwen3-8b": {"qkv": (6144, 4096), "o": (4096, 4096), "gate_up": (24576, 4096), "down": (4096, 12288)},
+    "qwen3-14b": {"qkv": (7168, 5120), "o": (5120, 5120), "gate_up": (34816, 5120), "down": (5120, 17408)},
+    "qwen3-32b": {"qkv": (10240, 5120), "o": (5120, 8192), "gate_up": (51200, 5120), "down": (5120, 25600)},
+}
+shapes = SHAPES[os.environ.get("MODEL", "qwen3-8b")]
 
 
 def bench(fn, x, ws):
