@@ -198,8 +198,14 @@ def _host_lib():
         if not os.path.exists(path):
             _HOST_LIB = False
             return None
-        lib = ctypes.CDLL(path)
-        vp, i32p = ctypes.c_void_p, ctypes.POINTER(ctypes.c_int32)
+        try:
+            lib = ctypes.CDLL(path)
+        except OSError as e:                  # built for another machine: use the Python allocator
+            import warnings
+            warnings.warn(f"cannot load {path} ({e}); falling back to the Python block manager")
+            _HOST_LIB = False
+            return None
+        vp = ctypes.c_void_p
         lib.mvl_bm_create.restype = vp
         lib.mvl_bm_create.argtypes = [ctypes.c_int, ctypes.c_int]
         lib.mvl_bm_destroy.argtypes = [vp]
