@@ -217,6 +217,24 @@ class ModelRunner:
         self._dec_dev = torch.zeros(self._dec_words, dtype=torch.int32, device=self.device)
         self._pre_host = None
         self._pre_dev = None
+        # single-sequence prefill of a few tokens (a short prompt, or a new chat turn behind a
+        # cached prefix) replays a hipGraph as decode does: fixed layout, one buffer
+        self.prefill_graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
+        self._pg_out: Dict[int, torch.Tensor] = {}
+        pg_max = cfg.prefill_graph_max_tokens if self.on_gpu and not cfg.enforce_eager else 0
+        pg_max = int(os.environ.get("MINIVLLM_PREFILL_GRAPH_MAX", pg_max))
+        pg_max = min(pg_max, 1024, cfg.max_num_batched_tokens, cfg.max_model_length)
+        self._pg_sizes = list(range(64, pg_max + 1, 64))        # = the prefill token buckets
+        self._pg_off = {}
+        if self._pg_sizes:
+            tmax, off = self._pg_sizes[-1], 0
+            for name, n in (("input_ids", tmax), ("positions", tmax), ("slot_mapping", tmax),
+                            ("cu_seqlens_q", 2), ("cu_seqlens_k", 2), ("temperatures", 1),
+                            ("misc", 4), ("block_tables", MB)):
+                self._pg_off[name] = (off, n)
+                off += (n + 3) // 4 * 4
+            self._pg_host = torch.zeros(off, dtype=torch.int32, pin_memory=True)
+            self._pg_dev = torch.zeros(off, dtype=torch.int32, device=self.device)
 
     def _ensure_prefill_buffers(self, words: int) -> None:
         if self._pre_host is None or self._pre_host.numel() < words:
@@ -256,6 +274,8 @@ class ModelRunner:
             torch.cuda.synchronize()
         # give the device memory back: another engine may be built in this process
         self.graphs.clear()
+        self.prefill_graphs.clear()
+        self._pg_out = {}
         self._graph_out = {}
         self.graph_pool = None
         for layer in self.model.model.layers:
@@ -537,7 +557,9 @@ class ModelRunner:
 
     # -------------------------------------------------------------- execute
     def execute(self, b: Batch, warmup: bool = False) -> Optional[List[int]]:
-        if b.is_prefill:
+        if b.is_prefill and not warmup and b.num_seqs == 1 and b.num_tokens in self.prefill_graphs:
+            tokens = self._replay_prefill_graph(b)
+        elif b.is_prefill:
             t = self._upload_prefill(b)
             set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
                         max_seqlen_q=b.max_seqlen_q, max_seqlen_k=b.max_seqlen_k,
@@ -651,3 +673,73 @@ class ModelRunner:
             self.graphs[bs] = g
             self._graph_out[bs] = out
         torch.cuda.synchronize()
+        self._capture_prefill_graphs()
+
+    def _pg_tensors(self, tb: int) -> dict:
+        d = self._pg_dev
+
+        def v(name, n=None):
+            off, size = self._pg_off[name]
+            return d[off:off + (size if n is None else n)]
+        return dict(input_ids=v("input_ids", tb), positions=v("positions", tb),
+                    slot_mapping=v("slot_mapping", tb), cu_seqlens_q=v("cu_seqlens_q"),
+                    cu_seqlens_k=v("cu_seqlens_k"),
+                    temperatures=v("temperatures").view(torch.float32), step=v("misc"),
+                    block_tables=v("block_tables").view(1, self.max_blocks_per_seq))
+
+    def _capture_prefill_graphs(self) -> None:
+        """One graph per token bucket for a prefill step of ONE sequence (any cached prefix:
+        attention goes through the block table and reads the lengths from device memory).  An
+        eager prefill step costs ~6 ms of host launches however small it is; replayed, a short
+        prompt is bound by the GPU again."""
+        if not self._pg_sizes:
+            return
+        host = self._pg_host.numpy()
+        host[:] = 0
+        for name in ("slot_mapping", "block_tables"):
+            o, n = self._pg_off[name]
+            host[o:o + n] = -1
+        # a harmless one-token sequence: reads block 0, writes no KV (slot -1)
+        for name in ("cu_seqlens_q", "cu_seqlens_k"):
+            host[self._pg_off[name][0] + 1] = 1
+        host[self._pg_off["block_tables"][0]] = 0
+        self._pg_dev.copy_(self._pg_host)
+        for tb in reversed(self._pg_sizes):
+            t = self._pg_tensors(tb)
+
+            def step():
+                set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
+                            max_seqlen_q=tb, max_seqlen_k=self.cfg.max_model_length,
+                            slot_mapping=t["slot_mapping"], block_tables=t["block_tables"],
+                            positions=t["positions"], num_seqs=1, has_prefix=True)
+                out = self._forward_and_sample(t)
+                reset_context()
+                return out
+            step()
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
+                out = step()
+            self.prefill_graphs[tb] = g
+            self._pg_out[tb] = out
+        torch.cuda.synchronize()
+
+    def _replay_prefill_graph(self, b: Batch) -> torch.Tensor:
+        a = b.arrays
+        tb = b.num_tokens
+        host = self._pg_host.numpy()
+        for name in ("input_ids", "positions", "slot_mapping", "cu_seqlens_q", "cu_seqlens_k"):
+            o, _ = self._pg_off[name]
+            host[o:o + a[name].size] = a[name]
+        o, _ = self._pg_off["temperatures"]
+        host[o] = a["temperatures"].astype(np.float32).view(np.int32)[0]
+        host[self._pg_off["misc"][0]] = b.step
+        o, n = self._pg_off["block_tables"]
+        row = a["block_tables"].reshape(-1)
+        if row.size > n:
+            raise RuntimeError("sequence uses more KV blocks than max_model_length allows")
+        host[o:o + row.size] = row
+        host[o + row.size:o + n] = -1
+        self._pg_dev.copy_(self._pg_host, non_blocking=True)
+        self.prefill_graphs[tb].replay()
+        return self._pg_out[tb]

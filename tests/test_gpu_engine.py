@@ -204,3 +204,32 @@ def test_fp16_engine_generates_like_its_cpu_oracle(gpu):
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
     assert same / total > 0.85, (same, total)
+
+
+def test_single_sequence_prefill_graphs_match_eager_prefill(gpu):
+    """Prefill steps of one sequence with few new tokens replay a hipGraph: whole short
+    prompts, a new turn behind a cached prefix, and chunks of a long prompt must give the
+    tokens of the eager path."""
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    rng = np.random.default_rng(21)
+    prefix = rng.integers(0, 2048, size=96).tolist()                     # 6 full blocks of 16
+    prompts = [rng.integers(0, 2048, size=n).tolist() for n in (1, 37, 64, 65, 200, 256)] + \
+              [prefix + rng.integers(0, 2048, size=n).tolist() for n in (5, 40)] + \
+              [rng.integers(0, 2048, size=330).tolist()]                 # > 256: chunked below
+    sp = SamplingParams(temperature=0, max_tokens=6, ignore_eos=True)
+
+    def run(**kw):
+        eng = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[1], max_num_batched_tokens=256,
+                             **kw))
+        out = [eng.generate([p], sp)["token_ids"][0] for p in prompts]   # one at a time
+        n_graphs = len(eng.model_runner.prefill_graphs)
+        hits = eng.scheduler.block_manager.num_prefix_hits
+        eng.exit()
+        return out, n_graphs, hits
+
+    eager, n0, _ = run(prefill_graph_max_tokens=0)
+    graphed, n1, hits = run(prefill_graph_max_tokens=256)
+    assert n0 == 0 and n1 == 4 and hits >= 6
+    same = sum(int(a == b) for x, y in zip(eager, graphed) for a, b in zip(x, y))
+    total = sum(len(x) for x in eager)
+    assert same / total > 0.9, (same, total)
