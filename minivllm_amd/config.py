@@ -125,7 +125,7 @@ class EngineConfig:
     dist_backend: str = "auto"         # 'auto' | 'nccl' | 'gloo'
     # decode graphs
     graph_batch_sizes: Optional[list] = None
-    # prefill steps of ONE sequence with at most this many new tokens replay a hipGraph too
+    # prefill steps of at most 8 sequences and this many new tokens replay a hipGraph too
     # (buckets of 64 tokens, at most 1024; 0 = always launch prefill eagerly)
     prefill_graph_max_tokens: int = 1024
     log_stats: bool = False

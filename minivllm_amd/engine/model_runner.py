@@ -62,6 +62,9 @@ class Batch:
                     step=self.step, tables_unchanged=self.tables_unchanged)
 
 
+PREFILL_GRAPH_MAX_SEQS = 8        # sequences a graph-replayed prefill step can carry
+
+
 def _pad_block_tables(tables: List[List[int]]) -> np.ndarray:
     """[B, max blocks] int32, rows padded with -1, without a Python-level loop over rows."""
     n = np.fromiter(map(len, tables), np.int64, len(tables))
@@ -217,8 +220,8 @@ class ModelRunner:
         self._dec_dev = torch.zeros(self._dec_words, dtype=torch.int32, device=self.device)
         self._pre_host = None
         self._pre_dev = None
-        # single-sequence prefill of a few tokens (a short prompt, or a new chat turn behind a
-        # cached prefix) replays a hipGraph as decode does: fixed layout, one buffer
+        # a prefill step of a few sequences and few tokens (short prompts, a new chat turn
+        # behind a cached prefix) replays a hipGraph as decode does: fixed layout, one buffer
         self.prefill_graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
         self._pg_out: Dict[int, torch.Tensor] = {}
         pg_max = cfg.prefill_graph_max_tokens if self.on_gpu and not cfg.enforce_eager else 0
@@ -228,9 +231,10 @@ class ModelRunner:
         self._pg_off = {}
         if self._pg_sizes:
             tmax, off = self._pg_sizes[-1], 0
+            S = PREFILL_GRAPH_MAX_SEQS
             for name, n in (("input_ids", tmax), ("positions", tmax), ("slot_mapping", tmax),
-                            ("cu_seqlens_q", 2), ("cu_seqlens_k", 2), ("temperatures", 1),
-                            ("misc", 4), ("block_tables", MB)):
+                            ("cu_seqlens_q", S + 1), ("cu_seqlens_k", S + 1), ("temperatures", S),
+                            ("misc", 4), ("block_tables", S * MB)):
                 self._pg_off[name] = (off, n)
                 off += (n + 3) // 4 * 4
             self._pg_host = torch.zeros(off, dtype=torch.int32, pin_memory=True)
@@ -557,7 +561,8 @@ class ModelRunner:
 
     # -------------------------------------------------------------- execute
     def execute(self, b: Batch, warmup: bool = False) -> Optional[List[int]]:
-        if b.is_prefill and not warmup and b.num_seqs == 1 and b.num_tokens in self.prefill_graphs:
+        if (b.is_prefill and not warmup and b.num_seqs <= PREFILL_GRAPH_MAX_SEQS
+                and b.num_tokens in self.prefill_graphs):
             tokens = self._replay_prefill_graph(b)
         elif b.is_prefill:
             t = self._upload_prefill(b)
@@ -685,13 +690,15 @@ class ModelRunner:
                     slot_mapping=v("slot_mapping", tb), cu_seqlens_q=v("cu_seqlens_q"),
                     cu_seqlens_k=v("cu_seqlens_k"),
                     temperatures=v("temperatures").view(torch.float32), step=v("misc"),
-                    block_tables=v("block_tables").view(1, self.max_blocks_per_seq))
+                    block_tables=v("block_tables").view(PREFILL_GRAPH_MAX_SEQS,
+                                                        self.max_blocks_per_seq))
 
     def _capture_prefill_graphs(self) -> None:
-        """One graph per token bucket for a prefill step of ONE sequence (any cached prefix:
-        attention goes through the block table and reads the lengths from device memory).  An
-        eager prefill step costs ~6 ms of host launches however small it is; replayed, a short
-        prompt is bound by the GPU again."""
+        """One graph per token bucket for a prefill step of up to PREFILL_GRAPH_MAX_SEQS
+        sequences (any cached prefix: attention goes through the block table and reads the
+        lengths from device memory; unused sequence slots have length 0).  An eager prefill
+        step costs ~6 ms of host launches however small it is; replayed, a short prompt is
+        bound by the GPU again."""
         if not self._pg_sizes:
             return
         host = self._pg_host.numpy()
@@ -699,9 +706,10 @@ class ModelRunner:
         for name in ("slot_mapping", "block_tables"):
             o, n = self._pg_off[name]
             host[o:o + n] = -1
-        # a harmless one-token sequence: reads block 0, writes no KV (slot -1)
+        # a harmless one-token sequence (reads block 0, writes no KV: slot -1) + empty slots
         for name in ("cu_seqlens_q", "cu_seqlens_k"):
-            host[self._pg_off[name][0] + 1] = 1
+            o, n = self._pg_off[name]
+            host[o + 1:o + n] = 1
         host[self._pg_off["block_tables"][0]] = 0
         self._pg_dev.copy_(self._pg_host)
         for tb in reversed(self._pg_sizes):
@@ -711,7 +719,8 @@ class ModelRunner:
                 set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
                             max_seqlen_q=tb, max_seqlen_k=self.cfg.max_model_length,
                             slot_mapping=t["slot_mapping"], block_tables=t["block_tables"],
-                            positions=t["positions"], num_seqs=1, has_prefix=True)
+                            positions=t["positions"], num_seqs=PREFILL_GRAPH_MAX_SEQS,
+                            has_prefix=True)
                 out = self._forward_and_sample(t)
                 reset_context()
                 return out
@@ -726,20 +735,27 @@ class ModelRunner:
 
     def _replay_prefill_graph(self, b: Batch) -> torch.Tensor:
         a = b.arrays
-        tb = b.num_tokens
+        tb, B, S = b.num_tokens, b.num_seqs, PREFILL_GRAPH_MAX_SEQS
+        MB = self.max_blocks_per_seq
         host = self._pg_host.numpy()
-        for name in ("input_ids", "positions", "slot_mapping", "cu_seqlens_q", "cu_seqlens_k"):
+        for name in ("input_ids", "positions", "slot_mapping"):
             o, _ = self._pg_off[name]
-            host[o:o + a[name].size] = a[name]
-        o, _ = self._pg_off["temperatures"]
-        host[o] = a["temperatures"].astype(np.float32).view(np.int32)[0]
+            host[o:o + tb] = a[name]
+        for name in ("cu_seqlens_q", "cu_seqlens_k"):       # unused slots: zero-length sequences
+            o, n = self._pg_off[name]
+            host[o:o + B + 1] = a[name]
+            host[o + B + 1:o + n] = a[name][-1]
+        o, n = self._pg_off["temperatures"]
+        host[o:o + B] = a["temperatures"].astype(np.float32).view(np.int32)
+        host[o + B:o + n] = 0
         host[self._pg_off["misc"][0]] = b.step
         o, n = self._pg_off["block_tables"]
-        row = a["block_tables"].reshape(-1)
-        if row.size > n:
+        tab = host[o:o + n].reshape(S, MB)
+        mb = a["block_tables"].shape[1]
+        if mb > MB:
             raise RuntimeError("sequence uses more KV blocks than max_model_length allows")
-        host[o:o + row.size] = row
-        host[o + row.size:o + n] = -1
+        tab[:] = -1
+        tab[:B, :mb] = a["block_tables"]
         self._pg_dev.copy_(self._pg_host, non_blocking=True)
         self.prefill_graphs[tb].replay()
-        return self._pg_out[tb]
+        return self._pg_out[tb][:B]

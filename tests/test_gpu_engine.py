@@ -227,6 +227,19 @@ def test_single_sequence_prefill_graphs_match_eager_prefill(gpu):
         eng.exit()
         return out, n_graphs, hits
 
+    def run_batched(**kw):           # several short prompts admitted in ONE prefill step
+        eng = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[8], **kw))
+        short = [p for p in prompts if len(p) <= 110]
+        out = eng.generate(short, sp)["token_ids"]
+        steps = eng.stats.prefill_steps
+        eng.exit()
+        return out, steps
+
+    be, se = run_batched(prefill_graph_max_tokens=0)
+    bg, sg = run_batched(prefill_graph_max_tokens=1024)
+    assert se == sg == 1
+    assert sum(int(a == b) for x, y in zip(be, bg) for a, b in zip(x, y)) > 0.9 * sum(map(len, be))
+
     eager, n0, _ = run(prefill_graph_max_tokens=0)
     graphed, n1, hits = run(prefill_graph_max_tokens=256)
     assert n0 == 0 and n1 == 4 and hits >= 6
