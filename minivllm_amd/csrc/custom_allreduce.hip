@@ -9,6 +9,11 @@
 //   one-shot (small):  copy x -> my staging buffer | barrier | x = sum over ranks of staging
 //   two-shot:          copy | barrier | reduce MY 1/P slice from all ranks' staging into my
 //                      result buffer | barrier | gather the P reduced slices | barrier
+//   one-shot + norm:   the one-shot form for [rows, hidden] inputs with the consumer folded in:
+//                      a block owns whole rows, so after the sum it adds the residual stream,
+//                      stores the new residual and writes the RMS-normalised row - the
+//                      (residual add + RMSNorm) kernel that follows every row-parallel
+//                      projection of a decoder layer disappears for decode-sized batches
 //
 // Two-shot moves 2 (P-1)/P of the message over each rank's links (like reduce-scatter +
 // all-gather), one-shot (P-1) times the message but with one barrier less.
@@ -144,6 +149,107 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank
     if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
 }
 
+// One-shot all-reduce of x [rows, hidden] fused with `r = sum + residual; residual = r;
+// x = rms_norm(r) * gamma`.  Block b owns rows b, b + gridDim.x, ...  Rounding points and the
+// order of the sum of squares are those of the stand-alone kernels (all-reduce result rounded
+// to the storage dtype, then elementwise.hip's add + norm with the same thread <-> chunk
+// mapping), so both routes give the same bits.
+template <int CODE, int P, int MAXC>
+__global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
+        Peers pr, int rank, uint16_t* __restrict__ x, uint16_t* __restrict__ residual,
+        const uint16_t* __restrict__ gamma, int rows, int hidden, float eps) {
+    __shared__ float scratch[16];
+    Flags* mine = pr.flags[rank];
+    const uint32_t epoch = mine->epoch[blockIdx.x] + 1;
+    const int nchunk = hidden >> 3;
+    u32x4_t* xv = reinterpret_cast<u32x4_t*>(x);
+    u32x4_t* rv = reinterpret_cast<u32x4_t*>(residual);
+    u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
+
+    for (int row = blockIdx.x; row < rows; row += gridDim.x)
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + i * blockDim.x;
+            if (c < nchunk) st[(long)row * nchunk + c] = xv[(long)row * nchunk + c];
+        }
+    block_barrier<P>(pr, rank, 0, epoch, true);
+
+    const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(gamma);
+    for (int row = blockIdx.x; row < rows; row += gridDim.x) {
+        float v[MAXC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + i * blockDim.x;
+            if (c < nchunk) {
+                const long at = (long)row * nchunk + c;
+                u32x4_t pv[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    pv[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[at];
+                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int p = 0; p < P; ++p) accumulate<CODE>(acc, pv[p]);
+                unpack8<CODE>(pack8<CODE>(acc), v[i]);          // the all-reduce's rounding
+                float r[8];
+                unpack8<CODE>(rv[at], r);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[i][j] = DType<CODE>::to_float(DType<CODE>::from_float(v[i][j] + r[j]));
+                rv[at] = pack8<CODE>(v[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+            }
+        }
+        ss = block_sum(ss, scratch);
+        const float rstd = rsqrtf(ss / (float)hidden + eps);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + i * blockDim.x;
+            if (c < nchunk) {
+                float w[8], o[8];
+                unpack8<CODE>(wr[c], w);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rstd * w[j];
+                xv[(long)row * nchunk + c] = pack8<CODE>(o);
+            }
+        }
+    }
+    block_barrier<P>(pr, rank, 2, epoch, false);            // peers are done reading my staging
+    if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+}
+
+template <int CODE, int P>
+int launch_norm(const Peers& pr, int rank, void* x, void* residual, const void* gamma, int rows,
+                int hidden, float eps, hipStream_t st) {
+    const int nchunk = hidden / 8;
+    int threads = 64;                                       // as elementwise.hip's launch_rms
+    while (threads < nchunk && threads < 1024) threads <<= 1;
+    const int per = (nchunk + threads - 1) / threads;
+    const unsigned blocks = (unsigned)(rows < kMaxBlocks ? rows : kMaxBlocks);
+    auto X = (uint16_t*)x; auto R = (uint16_t*)residual; auto G = (const uint16_t*)gamma;
+    if (per <= 1)
+        all_reduce_norm_kernel<CODE, P, 1><<<blocks, threads, 0, st>>>(pr, rank, X, R, G, rows, hidden, eps);
+    else if (per <= 2)
+        all_reduce_norm_kernel<CODE, P, 2><<<blocks, threads, 0, st>>>(pr, rank, X, R, G, rows, hidden, eps);
+    else if (per <= 4)
+        all_reduce_norm_kernel<CODE, P, 4><<<blocks, threads, 0, st>>>(pr, rank, X, R, G, rows, hidden, eps);
+    else
+        return -1;
+    return MVL_CHECK_LAUNCH();
+}
+
+template <int CODE>
+int launch_norm_p(const Peers& pr, int world, int rank, void* x, void* residual, const void* gamma,
+                  int rows, int hidden, float eps, hipStream_t st) {
+    switch (world) {
+        case 2: return launch_norm<CODE, 2>(pr, rank, x, residual, gamma, rows, hidden, eps, st);
+        case 4: return launch_norm<CODE, 4>(pr, rank, x, residual, gamma, rows, hidden, eps, st);
+        case 8: return launch_norm<CODE, 8>(pr, rank, x, residual, gamma, rows, hidden, eps, st);
+        default: return -1;
+    }
+}
+
 template <int CODE, int P>
 int launch(const Peers& pr, int rank, void* x, long n_vec, bool two_shot, hipStream_t st) {
     const long per_block = two_shot ? n_vec / P : n_vec;
@@ -210,6 +316,27 @@ extern "C" int mvl_car_all_reduce(void* const* flags, void* const* stage, void* 
     auto st = (hipStream_t)stream;
     return dtype == 0 ? launch_p<0>(pr, world, rank, x, n_vec, two_shot != 0, st)
                       : launch_p<1>(pr, world, rank, x, n_vec, two_shot != 0, st);
+}
+
+// x [rows, hidden] (contiguous, this rank's partial sums) becomes rms_norm(sum + residual) * gamma;
+// residual [rows, hidden] becomes sum + residual.  One-shot only: rows * hidden * 2 bytes must
+// fit the staging buffer (the caller checks its size).
+extern "C" int mvl_car_all_reduce_norm(void* const* flags, void* const* stage, int world, int rank,
+                                       void* x, void* residual, const void* gamma, int rows,
+                                       int hidden, float eps, int dtype, void* stream) {
+    if (rows == 0) return 0;
+    if (world > kMaxRanks || hidden % 8 != 0 || hidden > 8 * 1024 * 4 ||
+        (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)gamma) & 15) != 0)
+        return -1;
+    Peers pr;
+    for (int p = 0; p < world; ++p) {
+        pr.flags[p] = (Flags*)flags[p];
+        pr.stage[p] = (uint16_t*)stage[p];
+        pr.result[p] = nullptr;
+    }
+    auto st = (hipStream_t)stream;
+    return dtype == 0 ? launch_norm_p<0>(pr, world, rank, x, residual, gamma, rows, hidden, eps, st)
+                      : launch_norm_p<1>(pr, world, rank, x, residual, gamma, rows, hidden, eps, st);
 }
 
 // Reads the sticky status word (0 = every barrier of every call so far completed).

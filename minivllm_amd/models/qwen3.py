@@ -63,9 +63,12 @@ class Qwen3Attention(nn.Module):
     def forward(self, positions: torch.Tensor, hidden: torch.Tensor) -> torch.Tensor:
         return self.attend(positions, self.qkv_proj(hidden))
 
-    def attend(self, positions: torch.Tensor, qkv: torch.Tensor) -> torch.Tensor:
+    def attend(self, positions: torch.Tensor, qkv: torch.Tensor,
+               defer_reduce: bool = False) -> torch.Tensor:
         """Everything after the QKV projection (the decoder layer may have produced ``qkv``
-        together with the preceding norm in one kernel)."""
+        together with the preceding norm in one kernel).  ``defer_reduce``: the caller feeds
+        the result into a norm with a residual, which may take over the TP all-reduce
+        (``RowParallelLinear.forward``)."""
         ctx = get_context()
         q, k, v = ops.qk_norm_rope_store(
             qkv, positions, self._rope[0].cos_sin_cache,
@@ -74,7 +77,7 @@ class Qwen3Attention(nn.Module):
             self.eps, self.num_heads, self.num_kv_heads, self.head_dim,
             self.attn.k_cache, self.attn.v_cache, ctx.slot_mapping)
         o = self.attn(q, k, v)
-        return self.o_proj(o)
+        return self.o_proj(o, defer_reduce=defer_reduce)
 
 
 class Qwen3MLP(nn.Module):
@@ -106,10 +109,10 @@ class Qwen3DecoderLayer(nn.Module):
         qkv_proj, gate_up = self.self_attn.qkv_proj, self.mlp.gate_up_proj
         qkv, residual = ops.norm_linear(hidden, residual, n1.weight, n1.eps, qkv_proj.weight,
                                         qkv_proj.bias, gamma_folded=n1.folded)
-        hidden = self.self_attn.attend(positions, qkv)
+        hidden = self.self_attn.attend(positions, qkv, defer_reduce=True)
         act, residual = ops.norm_linear(hidden, residual, n2.weight, n2.eps, gate_up.weight,
                                         gate_up.bias, swiglu=True, gamma_folded=n2.folded)
-        return self.mlp.down_proj(act), residual
+        return self.mlp.down_proj(act, defer_reduce=True), residual
 
     def fold_norm_weights(self) -> None:
         self.input_layernorm.fold_into(self.self_attn.qkv_proj.weight)

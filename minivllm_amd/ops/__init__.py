@@ -102,6 +102,10 @@ def norm_linear(x, residual, gamma, eps, weight, bias=None, swiglu=False, gamma_
     was multiplied by ``gamma`` along its input dimension at load time (``gamma`` itself is all
     ones then); only such weights can take the one-kernel path, every other case runs the norm
     kernel followed by the projection."""
+    if getattr(x, "_mvl_pending_reduce", False):       # row-parallel partial sum: reduce here
+        from ..parallel import group as pg
+        h, residual = pg.tp_reduce_add_rms_norm(x, residual, gamma, eps)
+        return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), residual
     if gamma_folded and fuses_norm_linear(x, weight, swiglu):
         return _hip().skinny_norm_linear(x, residual, eps, weight, bias, swiglu)
     if residual is None:

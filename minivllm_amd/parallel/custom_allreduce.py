@@ -12,6 +12,12 @@ maps the peers' allocations.  ``all_reduce(x)`` then launches the kernel on the 
 the call is hipGraph-capturable (pointers are fixed, the call counter lives in device memory).
 Messages that do not fit (too large, odd sizes, fp32) go to RCCL.
 
+``all_reduce_add_rms_norm`` is the one-shot form with its consumer folded in: the reference runs
+all-reduce, then a fused residual-add + RMSNorm kernel after every row-parallel projection
+(reference: src/myvllm/models/qwen3.py:191-195,216); for decode-sized batches the reducing kernel
+here owns whole rows, so it adds the residual stream and normalises the row itself and the second
+kernel disappears (two launches fewer per decoder layer).
+
 Opt-in: ``EngineConfig.custom_all_reduce`` / ``MINIVLLM_CUSTOM_AR=1``.
 """
 from __future__ import annotations
@@ -45,6 +51,9 @@ class CustomAllReduce:
         lib.mvl_car_status.argtypes = [vp]
         lib.mvl_car_all_reduce.argtypes = [ctypes.POINTER(vp)] * 3 + [
             ctypes.c_int, ctypes.c_int, vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp]
+        lib.mvl_car_all_reduce_norm.argtypes = [ctypes.POINTER(vp)] * 2 + [
+            ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
+            ctypes.c_int, vp]
         self._hbytes = lib.mvl_car_ipc_handle_bytes()
         torch.cuda.set_device(device)
         # flags, staging, result: fine-grained (uncached) allocations, coherent across the GPUs
@@ -85,6 +94,7 @@ class CustomAllReduce:
         self._raise_if_any_failed(self._exchange(err))   # also: every mapping exists from here on
         self._flags, self._stage, self._result = tables
         self.calls = 0
+        self.fused_norm_calls = 0
 
     def _exchange(self, obj) -> list:
         out: List[Optional[object]] = [None] * self.world
@@ -126,6 +136,30 @@ class CustomAllReduce:
         self.calls += 1
         return x
 
+    def fits_norm(self, x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor) -> bool:
+        """Whether ``all_reduce_add_rms_norm`` takes these operands (one-shot sized, whole
+        contiguous rows, 16-byte aligned)."""
+        return (x.dim() == 2 and self.fits(x) and x.numel() * 2 <= ONE_SHOT_MAX_BYTES
+                and x.shape[1] % 8 == 0 and x.shape[1] <= 32768
+                and residual.shape == x.shape and residual.dtype == x.dtype
+                and residual.is_contiguous() and residual.data_ptr() % 16 == 0
+                and gamma.dtype == x.dtype and gamma.is_contiguous()
+                and gamma.numel() == x.shape[1] and gamma.data_ptr() % 16 == 0)
+
+    def all_reduce_add_rms_norm(self, x: torch.Tensor, residual: torch.Tensor,
+                                gamma: torch.Tensor, eps: float):
+        """``r = sum over ranks of x + residual``; ``residual <- r`` and ``x <- rms_norm(r) *
+        gamma``, both in place, in one kernel.  Same bits as ``all_reduce`` followed by the
+        fused add + norm kernel.  Returns ``(x, residual)``."""
+        rc = self._lib.mvl_car_all_reduce_norm(
+            self._flags, self._stage, self.world, self.rank, x.data_ptr(), residual.data_ptr(),
+            gamma.data_ptr(), x.shape[0], x.shape[1], float(eps),
+            0 if x.dtype == torch.bfloat16 else 1, torch.cuda.current_stream().cuda_stream)
+        self._ck(rc, "launch")
+        self.calls += 1
+        self.fused_norm_calls += 1
+        return x, residual
+
     def self_test(self) -> bool:
         """All-reduce known integer patterns through both data paths and compare with the exact
         sums (collective call; the result is this rank's own verdict)."""
@@ -140,6 +174,18 @@ class CustomAllReduce:
                 self.all_reduce(x)
                 want = base.float() * P + P * (P - 1) / 2
                 ok = ok and bool((x.float() == want).all())
+        # the fused form against the two-kernel route it replaces (same bits expected)
+        from minivllm_amd.ops import hip
+        g = torch.Generator(device=self.device).manual_seed(4321)
+        base = torch.randn(5, 1024, device=self.device, dtype=torch.bfloat16, generator=g)
+        res0 = torch.randn(5, 1024, device=self.device, dtype=torch.bfloat16, generator=g)
+        gamma = torch.rand(1024, device=self.device, dtype=torch.bfloat16, generator=g) + 0.5
+        x1, r1 = base * (self.rank + 1), res0.clone()
+        x2, r2 = x1.clone(), res0.clone()
+        self.all_reduce(x1)
+        h1, r1 = hip.add_rms_norm(x1, r1, gamma, 1e-6)
+        h2, r2 = self.all_reduce_add_rms_norm(x2, r2, gamma, 1e-6)
+        ok = ok and bool(torch.equal(h1, h2)) and bool(torch.equal(r1, r2))
         return ok and self.healthy()
 
     def healthy(self) -> bool:

@@ -156,6 +156,43 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
+def mark_pending_reduce(x: torch.Tensor) -> torch.Tensor:
+    """Tag a row-parallel partial sum whose all-reduce is left to its consumer
+    (``tp_reduce_add_rms_norm``)."""
+    x._mvl_pending_reduce = True
+    return x
+
+
+def is_pending_reduce(x: torch.Tensor) -> bool:
+    return getattr(x, "_mvl_pending_reduce", False)
+
+
+def can_defer_reduce(rows: int, hidden: int, dtype: torch.dtype, on_gpu: bool) -> bool:
+    """True when the all-reduce of a [rows, hidden] row-parallel partial sum can be folded into
+    the (residual add + RMSNorm) that consumes it: the peer-to-peer kernel is active and the
+    tensor is one-shot sized.  The operands themselves are checked again at the consumer."""
+    if _CUSTOM_AR is None or not on_gpu or dtype not in (torch.bfloat16, torch.float16):
+        return False
+    from .custom_allreduce import ONE_SHOT_MAX_BYTES
+    n = rows * hidden
+    return 0 < n * 2 <= ONE_SHOT_MAX_BYTES and n % (8 * _TP_SIZE) == 0 and hidden % 8 == 0
+
+
+def tp_reduce_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor,
+                           eps: float):
+    """Consumer of a pending partial sum: ``(rms_norm(all_reduce(x) + residual) * gamma,
+    all_reduce(x) + residual)``, as one peer-to-peer kernel when the operands allow it and as
+    all-reduce + fused add/norm otherwise."""
+    x._mvl_pending_reduce = False
+    if residual is not None and _CUSTOM_AR is not None and _CUSTOM_AR.fits_norm(x, residual, gamma):
+        return _CUSTOM_AR.all_reduce_add_rms_norm(x, residual, gamma, eps)
+    from .. import ops
+    x = tp_all_reduce(x)
+    if residual is None:
+        return ops.rms_norm(x, gamma, eps), x
+    return ops.add_rms_norm(x, residual, gamma, eps)
+
+
 def _all_gather_parts(x: torch.Tensor) -> List[torch.Tensor]:
     src = x.cpu() if (_HOST_STAGED and x.is_cuda) else x.contiguous()
     parts: List[torch.Tensor] = [torch.empty_like(src) for _ in range(_TP_SIZE)]

@@ -34,26 +34,65 @@ def _worker(rank, world, port, q):
                 want = sum(parts)
                 got = car.all_reduce(x).float().cpu()
                 worst = max(worst, float((got - want).abs().max() / (want.abs().max() + 1e-6)))
+        # all-reduce fused with residual add + RMSNorm against the two kernels it replaces
+        # (same bits) and against fp32 math
+        from minivllm_amd.ops import hip
+        fused_exact, fused_err = True, 0.0
+        for dtype in (torch.bfloat16, torch.float16):
+            for rows, hidden in ((1, 4096), (7, 1024), (32, 4096), (16, 5120), (3, 12288), (64, 64)):
+                g = torch.Generator(device="cuda").manual_seed(77 * rank + rows + hidden)
+                x = torch.randn(rows, hidden, device="cuda", dtype=dtype, generator=g)
+                gs = torch.Generator(device="cuda").manual_seed(rows + hidden)      # same on both ranks
+                res = torch.randn(rows, hidden, device="cuda", dtype=dtype, generator=gs)
+                gamma = (torch.rand(hidden, device="cuda", generator=gs) + 0.5).to(dtype)
+                assert car.fits_norm(x, res, gamma)
+                mine = x.float().cpu()
+                parts = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(parts, mine)
+                x1, r1 = x.clone(), res.clone()
+                car.all_reduce(x1)
+                h1, r1 = hip.add_rms_norm(x1, r1, gamma, 1e-6)
+                h2, r2 = car.all_reduce_add_rms_norm(x.clone(), res.clone(), gamma, 1e-6)
+                fused_exact &= bool(torch.equal(h1, h2)) and bool(torch.equal(r1, r2))
+                r32 = sum(parts).cuda() + res.float()
+                h32 = r32 * torch.rsqrt(r32.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma.float()
+                fused_err = max(fused_err, float((h2.float() - h32).abs().max()),
+                                float((r2.float() - r32).abs().max() / 4))
+        assert not car.fits_norm(torch.zeros(64, 4096, device="cuda", dtype=torch.bfloat16),
+                                 torch.zeros(64, 4096, device="cuda", dtype=torch.bfloat16),
+                                 torch.ones(4096, device="cuda", dtype=torch.bfloat16))
+        assert fused_exact, "fused all-reduce + norm differs from all-reduce then norm"
+        assert fused_err < 0.08, fused_err
         # graph replay: three calls of different sizes in one graph, replayed on fresh inputs
         bufs = [torch.zeros(n, device="cuda", dtype=torch.bfloat16) for n in (4096, 256 * 4096, 64)]
+        fx = torch.zeros(8, 256, device="cuda", dtype=torch.bfloat16)
+        fr = torch.zeros(8, 256, device="cuda", dtype=torch.bfloat16)
+        ones = torch.ones(256, device="cuda", dtype=torch.bfloat16)
         for b in bufs:
             car.all_reduce(b)                                # warm-up outside capture
+        car.all_reduce_add_rms_norm(fx, fr, ones, 1e-6)
         torch.cuda.synchronize()
         dist.barrier()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, capture_error_mode="thread_local"):
             for b in bufs:
                 car.all_reduce(b)
+            car.all_reduce_add_rms_norm(fx, fr, ones, 1e-6)
         graph_ok = True
         for it in range(3):
             for b in bufs:
                 b.fill_(float(rank + 1 + it))
+            fx.fill_(float(rank + 1 + it))
+            fr.fill_(1.0)
             torch.cuda.synchronize()
             dist.barrier()
             g.replay()
             torch.cuda.synchronize()
             expect = float(sum(r + 1 + it for r in range(world)))
             graph_ok &= all(bool((b.float() == expect).all()) for b in bufs)
+            # constant rows: the residual becomes sum + 1 and the normalised row is all ones
+            graph_ok &= bool((fr.float() == expect + 1.0).all())
+            graph_ok &= bool((fx.float() - 1.0).abs().max() < 1e-2)
             dist.barrier()
         healthy = car.healthy()
         assert not car.fits(torch.zeros(24, device="cuda", dtype=torch.float32))

@@ -137,7 +137,10 @@ def test_tp2_on_one_gpu_matches_tp1(gpu, p2p_allreduce):
         assert pg.custom_all_reduce() is not None
     got = two.generate(prompts, sp)["token_ids"]
     if p2p_allreduce:
-        assert pg.custom_all_reduce().calls > 0 and pg.custom_all_reduce().healthy()
+        car = pg.custom_all_reduce()
+        assert car.calls > 0 and car.healthy()
+        # decode steps: the all-reduce after o_proj / down_proj ran fused with add + RMSNorm
+        assert car.fused_norm_calls > 0
     two.exit()
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
