@@ -201,6 +201,25 @@ class Scheduler:
         self.waiting.appendleft(seq)
         self.num_preemptions += 1
 
+    def abort(self, seq: Sequence) -> bool:
+        """Drop a request wherever it is queued (a client went away): its KV blocks return to
+        the pool (full blocks stay in the prefix cache).  False when it had already left."""
+        found = False
+        for q in (self.waiting, self.prefilling, self.running):
+            for i, s in enumerate(q):
+                if s is seq:
+                    del q[i]
+                    found = True
+                    break
+        if not found:
+            return False
+        self._decode_batch = None
+        seq.prefill_end = None
+        if seq.block_table:
+            self.block_manager.deallocate(seq)
+        seq.status = SequenceStatus.FINISHED
+        return True
+
     # ---------------------------------------------------------- postprocess
     def postprocess(self, seqs: List[Sequence], token_ids: List[int]) -> List[Sequence]:
         finished = []

@@ -1,0 +1,277 @@
+"""OpenAI-style HTTP front end for ``AsyncLLMEngine``.
+
+    python -m minivllm_amd.serve.api_server --model-preset qwen3-8b --port 8000 \\
+           [--checkpoint-path /path/to/Qwen3-8B] [--world-size 8] [--max-num-sequences 1024]
+
+Endpoints: ``POST /v1/completions`` and ``POST /v1/chat/completions`` (JSON in, JSON or
+server-sent events out with ``"stream": true``), ``GET /v1/models``, ``GET /health``,
+``GET /metrics`` (Prometheus text format).  A client that disconnects mid-stream aborts its
+request, which returns its KV blocks to the pool.  Prompts may be text or token-id lists (random
+weights and the byte-level fallback tokenizer make token ids the practical choice offline).
+
+The reference has no server (its entry point is the offline demo, reference: main.py:43-71); the
+request fields follow the OpenAI completions API so existing clients work unchanged.
+"""
+from __future__ import annotations
+
+import argparse
+import asyncio
+import json
+import time
+import uuid
+from typing import List, Optional, Union
+
+from fastapi import FastAPI, HTTPException, Request
+from fastapi.responses import JSONResponse, Response, StreamingResponse
+
+from minivllm_amd.sampling_parameters import SamplingParams
+from minivllm_amd.serve.async_engine import AsyncLLMEngine, RequestHandle
+
+
+class _TextStream:
+    """Incremental detokenisation: text is released only up to the last complete character
+    (a multi-byte character may span tokens)."""
+
+    def __init__(self, tokenizer):
+        self.tok, self.ids, self.sent = tokenizer, [], 0
+
+    def push(self, tokens: List[int], final: bool = False) -> str:
+        self.ids.extend(tokens)
+        text = self.tok.decode(self.ids, skip_special_tokens=True)
+        if not final:
+            while text.endswith("�"):
+                text = text[:-1]
+        delta, self.sent = text[self.sent:], max(self.sent, len(text))
+        return delta
+
+
+def _metrics():
+    from prometheus_client import CollectorRegistry, Counter, Gauge, Histogram
+    reg = CollectorRegistry()
+    lat = (0.005, 0.01, 0.02, 0.05, 0.1, 0.2, 0.5, 1, 2, 5, 10, 30, 60)
+    return reg, {
+        "requests": Counter("minivllm_requests", "requests by outcome", ["finish_reason"], registry=reg),
+        "prompt_tokens": Counter("minivllm_prompt_tokens", "prompt tokens received", registry=reg),
+        "generated_tokens": Counter("minivllm_generated_tokens", "tokens generated", registry=reg),
+        "ttft": Histogram("minivllm_time_to_first_token_seconds", "submit -> first token",
+                          buckets=lat, registry=reg),
+        "e2e": Histogram("minivllm_request_seconds", "submit -> finished", buckets=lat, registry=reg),
+        "running": Gauge("minivllm_running_requests", "sequences holding KV blocks", registry=reg),
+        "waiting": Gauge("minivllm_waiting_requests", "sequences queued for prefill", registry=reg),
+        "kv_free": Gauge("minivllm_kv_blocks_free", "free KV cache blocks", registry=reg),
+        "prefill_tok_s": Gauge("minivllm_prefill_tokens_per_second", "engine average", registry=reg),
+        "decode_tok_s": Gauge("minivllm_decode_tokens_per_second", "engine average", registry=reg),
+    }
+
+
+def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
+    app = FastAPI(title="minivllm_amd")
+    registry, m = _metrics()
+    max_len = engine.engine.cfg.max_model_length
+
+    def _account(h: RequestHandle) -> None:
+        m["requests"].labels(h.finish_reason or "unknown").inc()
+        m["prompt_tokens"].inc(h.num_prompt_tokens)
+        m["generated_tokens"].inc(len(h.token_ids))
+        if h.first_token_at is not None:
+            m["ttft"].observe(h.first_token_at - h.submitted_at)
+        if h.finished_at is not None:
+            m["e2e"].observe(h.finished_at - h.submitted_at)
+
+    def _params(body: dict) -> SamplingParams:
+        max_tokens = body.get("max_tokens")
+        if max_tokens is None:
+            max_tokens = body.get("max_completion_tokens")
+        try:
+            return SamplingParams(temperature=float(body.get("temperature", 1.0)),
+                                  max_tokens=16 if max_tokens is None else int(max_tokens),
+                                  ignore_eos=bool(body.get("ignore_eos", False)))
+        except (TypeError, ValueError) as e:
+            raise HTTPException(400, str(e))
+
+    def _prompts(p) -> List[Union[str, List[int]]]:
+        if isinstance(p, str):
+            return [p]
+        if isinstance(p, list) and p and all(isinstance(t, int) for t in p):
+            return [p]
+        if isinstance(p, list) and p and all(
+                isinstance(x, str) or (isinstance(x, list) and x and all(isinstance(t, int) for t in x))
+                for x in p):
+            return list(p)
+        raise HTTPException(400, "prompt must be a string, a token-id list, or a list of those")
+
+    def _usage(hs: List[RequestHandle]) -> dict:
+        pt, ct = sum(h.num_prompt_tokens for h in hs), sum(len(h.token_ids) for h in hs)
+        return {"prompt_tokens": pt, "completion_tokens": ct, "total_tokens": pt + ct}
+
+    async def _collect(h: RequestHandle) -> None:
+        try:
+            async for _ in h:
+                pass
+        finally:
+            if not h.finished:
+                h.cancel()
+
+    async def _run_all(hs: List[RequestHandle]) -> None:
+        try:
+            await asyncio.gather(*(_collect(h) for h in hs))
+        except ValueError as e:                             # rejected by the scheduler
+            raise HTTPException(400, str(e))
+        finally:
+            for h in hs:
+                if h.finished:
+                    _account(h)
+                else:
+                    h.cancel()
+
+    def _sse(obj) -> bytes:
+        return f"data: {json.dumps(obj)}\n\n".encode()
+
+    async def _stream(hs: List[RequestHandle], make_chunk, request: Request):
+        """Interleave the token streams of ``hs`` as server-sent events."""
+        out: asyncio.Queue = asyncio.Queue()
+
+        async def pump(i: int, h: RequestHandle):
+            ts = _TextStream(engine.tokenizer)
+            try:
+                async for toks in h:
+                    await out.put(make_chunk(i, ts.push(toks), toks, None))
+                await out.put(make_chunk(i, ts.push([], final=True), [], h.finish_reason))
+            except Exception as e:
+                await out.put({"error": {"message": str(e), "type": type(e).__name__}})
+            await out.put(None)
+
+        tasks = [asyncio.ensure_future(pump(i, h)) for i, h in enumerate(hs)]
+        live = len(tasks)
+        try:
+            while live:
+                item = await out.get()
+                if item is None:
+                    live -= 1
+                    continue
+                yield _sse(item)
+            yield b"data: [DONE]\n\n"
+        finally:                                            # also runs when the client went away
+            for t in tasks:
+                t.cancel()
+            for h in hs:
+                if not h.finished:
+                    h.cancel()
+                else:
+                    _account(h)
+
+    @app.get("/health")
+    async def health():
+        return {"status": "ok"}
+
+    @app.get("/v1/models")
+    async def models():
+        return {"object": "list", "data": [{"id": model_name, "object": "model",
+                                            "owned_by": "minivllm_amd", "max_model_len": max_len}]}
+
+    @app.get("/metrics")
+    async def metrics():
+        from prometheus_client import generate_latest
+        st = engine.stats()
+        m["running"].set(st["running"]); m["waiting"].set(st["waiting"])
+        m["kv_free"].set(st["kv_blocks_free"])
+        m["prefill_tok_s"].set(st["prefill_tok_s"]); m["decode_tok_s"].set(st["decode_tok_s"])
+        return Response(generate_latest(registry), media_type="text/plain; version=0.0.4")
+
+    @app.post("/v1/completions")
+    async def completions(request: Request):
+        body = await request.json()
+        sp, prompts = _params(body), _prompts(body.get("prompt"))
+        loop = asyncio.get_running_loop()
+        rid, created = f"cmpl-{uuid.uuid4().hex}", int(time.time())
+        hs = [engine.submit(p, sp, loop=loop) for p in prompts]
+        if body.get("stream"):
+            def chunk(i, text, toks, reason):
+                return {"id": rid, "object": "text_completion", "created": created,
+                        "model": model_name,
+                        "choices": [{"index": i, "text": text, "token_ids": toks,
+                                     "finish_reason": reason}]}
+            return StreamingResponse(_stream(hs, chunk, request), media_type="text/event-stream")
+        await _run_all(hs)
+        tok = engine.tokenizer
+        return JSONResponse({
+            "id": rid, "object": "text_completion", "created": created, "model": model_name,
+            "choices": [{"index": i, "text": tok.decode(h.token_ids, skip_special_tokens=True),
+                         "token_ids": h.token_ids, "finish_reason": h.finish_reason}
+                        for i, h in enumerate(hs)],
+            "usage": _usage(hs)})
+
+    @app.post("/v1/chat/completions")
+    async def chat(request: Request):
+        body = await request.json()
+        msgs = body.get("messages")
+        if not isinstance(msgs, list) or not msgs:
+            raise HTTPException(400, "messages must be a non-empty list")
+        tok = engine.tokenizer
+        try:
+            text = tok.apply_chat_template(msgs, tokenize=False, add_generation_prompt=True)
+        except Exception:                                   # tokenizer without a template
+            text = "".join(f"<|im_start|>{x['role']}\n{x['content']}<|im_end|>\n" for x in msgs)
+            text += "<|im_start|>assistant\n"
+        sp = _params(body)
+        rid, created = f"chatcmpl-{uuid.uuid4().hex}", int(time.time())
+        h = engine.submit(text, sp, loop=asyncio.get_running_loop())
+        if body.get("stream"):
+            first = [True]
+
+            def chunk(i, piece, toks, reason):
+                delta = {"content": piece}
+                if first[0]:
+                    delta["role"], first[0] = "assistant", False
+                return {"id": rid, "object": "chat.completion.chunk", "created": created,
+                        "model": model_name,
+                        "choices": [{"index": i, "delta": delta, "finish_reason": reason}]}
+            return StreamingResponse(_stream([h], chunk, request), media_type="text/event-stream")
+        await _run_all([h])
+        return JSONResponse({
+            "id": rid, "object": "chat.completion", "created": created, "model": model_name,
+            "choices": [{"index": 0, "finish_reason": h.finish_reason,
+                         "message": {"role": "assistant",
+                                     "content": tok.decode(h.token_ids, skip_special_tokens=True)}}],
+            "usage": _usage([h])})
+
+    return app
+
+
+def main(argv: Optional[List[str]] = None) -> None:
+    ap = argparse.ArgumentParser(description="OpenAI-style server on minivllm_amd")
+    ap.add_argument("--model-preset", default="qwen3-0.6b")
+    ap.add_argument("--checkpoint-path", default=None)
+    ap.add_argument("--tokenizer", default=None, help="local HF tokenizer directory")
+    ap.add_argument("--host", default="127.0.0.1")
+    ap.add_argument("--port", type=int, default=8000)
+    ap.add_argument("--world-size", type=int, default=1, help="tensor-parallel degree")
+    ap.add_argument("--max-num-sequences", type=int, default=256)
+    ap.add_argument("--max-num-batched-tokens", type=int, default=16384)
+    ap.add_argument("--max-model-length", type=int, default=8192)
+    ap.add_argument("--min-prefill-tokens", type=int, default=0)
+    ap.add_argument("--device", default="cuda")
+    ap.add_argument("--enforce-eager", action="store_true")
+    a = ap.parse_args(argv)
+    cfg = {"model_preset": a.model_preset, "world_size": a.world_size,
+           "max_num_sequences": a.max_num_sequences,
+           "max_num_batched_tokens": a.max_num_batched_tokens,
+           "max_model_length": a.max_model_length, "min_prefill_tokens": a.min_prefill_tokens,
+           "device": a.device, "enforce_eager": a.enforce_eager or a.device != "cuda",
+           "log_stats": False}
+    if a.checkpoint_path:
+        cfg["checkpoint_path"] = a.checkpoint_path
+    if a.tokenizer or a.checkpoint_path:
+        cfg["model_name_or_path"] = a.tokenizer or a.checkpoint_path
+    if a.device != "cuda":
+        cfg["dtype"] = "float32"
+    import uvicorn
+    engine = AsyncLLMEngine(cfg)
+    try:
+        uvicorn.run(create_app(engine, a.model_preset), host=a.host, port=a.port, log_level="info")
+    finally:
+        engine.shutdown(drain=False)
+
+
+if __name__ == "__main__":
+    main()

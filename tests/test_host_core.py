@@ -327,3 +327,23 @@ def test_prefill_is_deferred_until_enough_tokens_can_be_admitted():
     sch.add_sequence(one)
     batch, is_prefill = sch.schedule()
     assert is_prefill and batch == [one]                       # everything that waits fits
+
+
+def test_abort_removes_a_request_from_any_queue_and_returns_its_blocks():
+    sch = make_sched(blocks=16, max_seqs=2, max_tokens=16, chunked=True)
+    a, b, c = (seq(range(i * 50, i * 50 + 10), max_tokens=6) for i in range(3))
+    for s in (a, b, c):
+        sch.add_sequence(s)
+    batch, is_prefill = sch.schedule()                        # a whole, b cut after 6 tokens
+    assert is_prefill and batch == [a, b] and list(sch.prefilling) == [b]
+    sch.postprocess(batch, [1, 0])
+    free = sch.block_manager.num_free_blocks
+    assert sch.abort(b) and not sch.prefilling                # mid-prefill
+    assert sch.block_manager.num_free_blocks > free and b.block_table == []
+    assert sch.abort(c) and not sch.waiting                   # never admitted
+    assert not sch.abort(c)                                   # already gone
+    batch, is_prefill = sch.schedule()
+    assert not is_prefill and batch == [a]
+    assert sch.abort(a) and sch.is_finished()                 # while decoding
+    assert sch.block_manager.num_free_blocks == 16
+    assert a.status == SequenceStatus.FINISHED

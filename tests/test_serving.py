@@ -1,0 +1,150 @@
+"""Online serving layer on the CPU path: the background engine loop (requests arriving while
+others run, token streaming, abort, rejection) and the OpenAI-style HTTP front end."""
+import asyncio
+import json
+import threading
+import time
+
+import pytest
+
+from minivllm_amd.sampling_parameters import SamplingParams
+
+CFG = {"model_preset": "qwen3-tiny", "device": "cpu", "dtype": "float32", "enforce_eager": True,
+       "max_num_sequences": 4, "max_num_batched_tokens": 64, "block_size": 16,
+       "max_cached_blocks": 64, "max_model_length": 96, "eos": -1, "seed": 3}
+
+
+def _prompts(n):
+    return [[(7 * i + 3 * j) % 200 + 1 for j in range(5 + 3 * i)] for i in range(n)]
+
+
+@pytest.fixture(scope="module")
+def offline_tokens():
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    eng = LLMEngine(dict(CFG))
+    out = eng.generate(_prompts(6), SamplingParams(temperature=0, max_tokens=10, ignore_eos=True))
+    eng.exit()
+    return out["token_ids"]
+
+
+@pytest.fixture()
+def server_engine():
+    from minivllm_amd.serve import AsyncLLMEngine
+    eng = AsyncLLMEngine(dict(CFG))
+    yield eng
+    eng.shutdown(drain=False)
+
+
+def test_requests_arriving_over_time_match_offline_generate(server_engine, offline_tokens):
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    handles = []
+    for i, p in enumerate(_prompts(6)):          # more requests than sequence slots, staggered
+        handles.append(server_engine.submit(p, sp))
+        if i % 2:
+            time.sleep(0.02)
+    got = [h.result(timeout=120) for h in handles]
+    assert got == offline_tokens
+    assert all(h.finish_reason == "length" and h.first_token_at is not None for h in handles)
+    st = server_engine.stats()
+    assert st["requests_finished"] == 6 and st["running"] == 0 and st["waiting"] == 0
+    assert st["kv_blocks_free"] == st["kv_blocks"]              # every block came back
+
+
+def test_streaming_chunks_concatenate_to_the_result(server_engine, offline_tokens):
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    h = server_engine.submit(_prompts(1)[0], sp)
+    chunks = list(h)
+    assert len(chunks) == 10 and all(len(c) == 1 for c in chunks)   # one token per engine step
+    assert [t for c in chunks for t in c] == offline_tokens[0] == h.token_ids
+
+
+def test_abort_frees_blocks_and_rejections_do_not_stop_the_loop(server_engine, offline_tokens):
+    long_sp = SamplingParams(temperature=0, max_tokens=80, ignore_eos=True)
+    victim = server_engine.submit(_prompts(1)[0], long_sp)
+    it = iter(victim)
+    next(it)                                        # it is decoding now
+    victim.cancel()
+    for _ in it:
+        pass
+    assert victim.finish_reason == "abort" and 0 < len(victim.token_ids) < 80
+    bad = server_engine.submit(list(range(1, 90)), SamplingParams(max_tokens=64))  # > max_model_length
+    with pytest.raises(ValueError):
+        bad.result(timeout=30)
+    assert bad.finish_reason == "error"
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    assert server_engine.generate(_prompts(2)[1], sp, timeout=60) == offline_tokens[1]
+    st = server_engine.stats()
+    assert st["requests_aborted"] == 1 and st["kv_blocks_free"] == st["kv_blocks"]
+
+
+def test_asyncio_consumers(server_engine, offline_tokens):
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+
+    async def one(p):
+        h = server_engine.submit(p, sp, loop=asyncio.get_running_loop())
+        out = []
+        async for toks in h:
+            out.extend(toks)
+        return out
+
+    async def main():
+        return await asyncio.gather(*(one(p) for p in _prompts(3)))
+
+    assert asyncio.run(main()) == offline_tokens[:3]
+
+
+def test_shutdown_drains_requests_in_flight(offline_tokens):
+    from minivllm_amd.serve import AsyncLLMEngine
+    eng = AsyncLLMEngine(dict(CFG))
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    hs = [eng.submit(p, sp) for p in _prompts(3)]
+    eng.shutdown(drain=True)
+    assert [h.result(timeout=1) for h in hs] == offline_tokens[:3]
+
+
+def test_http_api(server_engine, offline_tokens):
+    from fastapi.testclient import TestClient
+    from minivllm_amd.serve.api_server import create_app
+    client = TestClient(create_app(server_engine, "tiny"))
+    assert client.get("/health").json() == {"status": "ok"}
+    assert client.get("/v1/models").json()["data"][0]["id"] == "tiny"
+    ps = _prompts(2)
+    r = client.post("/v1/completions", json={"prompt": ps, "max_tokens": 10, "temperature": 0,
+                                             "ignore_eos": True})
+    assert r.status_code == 200, r.text
+    body = r.json()
+    assert [c["token_ids"] for c in body["choices"]] == offline_tokens[:2]
+    assert all(c["finish_reason"] == "length" for c in body["choices"])
+    assert body["usage"] == {"prompt_tokens": len(ps[0]) + len(ps[1]), "completion_tokens": 20,
+                             "total_tokens": len(ps[0]) + len(ps[1]) + 20}
+    # streaming: server-sent events, one chunk per token, then a closing chunk and [DONE]
+    toks, reasons, done = [], [], False
+    with client.stream("POST", "/v1/completions",
+                       json={"prompt": ps[0], "max_tokens": 10, "temperature": 0,
+                             "ignore_eos": True, "stream": True}) as resp:
+        assert resp.headers["content-type"].startswith("text/event-stream")
+        for line in resp.iter_lines():
+            if not line.startswith("data: "):
+                continue
+            if line == "data: [DONE]":
+                done = True
+                continue
+            ch = json.loads(line[6:])["choices"][0]
+            toks.extend(ch["token_ids"])
+            reasons.append(ch["finish_reason"])
+    assert done and toks == offline_tokens[0] and reasons[-1] == "length"
+    assert set(reasons[:-1]) == {None}
+    # chat endpoint goes through the tokenizer's chat template
+    r = client.post("/v1/chat/completions", json={
+        "messages": [{"role": "user", "content": "hi"}], "max_tokens": 4, "temperature": 0})
+    assert r.status_code == 200, r.text
+    msg = r.json()["choices"][0]
+    assert msg["message"]["role"] == "assistant" and r.json()["usage"]["completion_tokens"] <= 4
+    # bad requests are refused with 400 and the server keeps going
+    assert client.post("/v1/completions", json={"prompt": 5}).status_code == 400
+    assert client.post("/v1/completions", json={"prompt": "x", "max_tokens": 0}).status_code == 400
+    assert client.post("/v1/completions",
+                       json={"prompt": list(range(1, 95)), "max_tokens": 50}).status_code == 400
+    text = client.get("/metrics").text
+    assert 'minivllm_requests_total{finish_reason="length"}' in text
+    assert "minivllm_generated_tokens_total" in text and "minivllm_kv_blocks_free" in text
