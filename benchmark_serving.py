@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--max-batched-tokens", type=int, default=16384)
     ap.add_argument("--block-size", type=int, default=256)
     ap.add_argument("--min-prefill-tokens", type=int, default=0)
+    ap.add_argument("--max-prefill-delay-ms", type=float, default=0.0,
+                    help="hold a small prefill step this long so that arrivals share it")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -64,6 +66,7 @@ def main():
     cfg = EngineConfig(model=model, max_num_sequences=a.max_seqs,
                        max_num_batched_tokens=a.max_batched_tokens, block_size=a.block_size,
                        eos=-1, min_prefill_tokens=a.min_prefill_tokens,
+                       max_prefill_delay_ms=a.max_prefill_delay_ms,
                        enforce_eager=a.eager or not on_gpu,
                        max_model_length=int(in_lens.max() + out_lens.max()) + 8,
                        dtype=torch.bfloat16 if on_gpu else torch.float32, device=a.device,
@@ -102,6 +105,7 @@ def main():
            "config": {"input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
                       "max_seqs": a.max_seqs, "max_batched_tokens": a.max_batched_tokens,
                       "min_prefill_tokens": a.min_prefill_tokens,
+                      "max_prefill_delay_ms": a.max_prefill_delay_ms,
                       "dtype": str(cfg.dtype).replace("torch.", ""), "device": a.device}}
     print(json.dumps(res), flush=True)
     if a.json:

@@ -149,6 +149,10 @@ class EngineConfig:
     # > 0: while sequences are decoding, start a prefill step only when at least this many prompt
     # tokens can be admitted at once (0 = the reference policy: every newcomer interrupts decode)
     min_prefill_tokens: int = 0
+    # online serving: with min_prefill_tokens set, a newcomer that alone would make a small prefill
+    # step is held for at most this long so that requests arriving close together share one step
+    # (0 = only defer while sequence slots, not arrivals, are what limits the step)
+    max_prefill_delay_ms: float = 0.0
     # all-reduce decode-sized tensors with the peer-to-peer kernel (parallel/custom_allreduce.py)
     # instead of RCCL; larger tensors still go to RCCL.  Also switched on by MINIVLLM_CUSTOM_AR=1.
     custom_all_reduce: bool = False

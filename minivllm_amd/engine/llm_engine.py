@@ -81,7 +81,8 @@ class LLMEngine:
                                    self.model_runner.num_kv_blocks, cfg.block_size, cfg.eos,
                                    max_model_length=cfg.max_model_length,
                                    enable_chunked_prefill=cfg.enable_chunked_prefill,
-                                   min_prefill_tokens=cfg.min_prefill_tokens)
+                                   min_prefill_tokens=cfg.min_prefill_tokens,
+                                   max_prefill_delay_s=cfg.max_prefill_delay_ms / 1e3)
         self.tokenizer = load_tokenizer(cfg.model_name_or_path, cfg.model.vocab_size)
         self.stats = EngineStats()
         self._exited = False

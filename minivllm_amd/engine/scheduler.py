@@ -19,6 +19,7 @@ that reaches the end of the sequence yields a sampled token.
 """
 from __future__ import annotations
 
+import time
 from collections import deque
 from typing import Deque, List, Optional, Tuple
 
@@ -30,13 +31,17 @@ class Scheduler:
     def __init__(self, max_num_sequences: int, max_num_batched_tokens: int,
                  max_cached_blocks: int, block_size: int, eos: int,
                  max_model_length: Optional[int] = None, enable_chunked_prefill: bool = True,
-                 min_prefill_tokens: int = 0):
+                 min_prefill_tokens: int = 0, max_prefill_delay_s: float = 0.0):
         self.enable_chunked_prefill = enable_chunked_prefill
         # > 0: while sequences are decoding, newcomers are admitted only once this many prompt
         # tokens can go into one prefill step (or everything that waits fits).  The reference
         # interrupts the decode batch for every single newcomer (scheduler.py:29-41), which
         # turns a saturated server into an alternation of full decode steps and tiny prefills.
         self.min_prefill_tokens = min_prefill_tokens
+        # online arrivals: even when every waiting request would fit, a step below
+        # min_prefill_tokens is held back until the oldest waiting request is this old, so that
+        # requests arriving within the window are prefetched together
+        self.max_prefill_delay_s = max_prefill_delay_s
         # admitted (blocks allocated) but not yet completely prefetched, oldest first
         self.prefilling: Deque[Sequence] = deque()
         self.block_manager = make_block_manager(max_cached_blocks, block_size)
@@ -75,6 +80,7 @@ class Scheduler:
         if need > self.block_manager.num_blocks:
             raise ValueError(
                 f"request needs {need} KV blocks but the cache has {self.block_manager.num_blocks}")
+        seq.arrival_time = time.monotonic()
         self.waiting.append(seq)
         self._decode_batch = None
 
@@ -191,7 +197,14 @@ class Scheduler:
                 break
             tokens += len(seq)
             admitted += 1
-        return tokens < self.min_prefill_tokens and admitted < len(self.waiting)
+        if tokens >= self.min_prefill_tokens:
+            return False
+        if admitted < len(self.waiting):
+            return True                 # slots are the limit: wait until more of them free up
+        if self.max_prefill_delay_s > 0:
+            age = time.monotonic() - getattr(self.waiting[0], "arrival_time", 0.0)
+            return age < self.max_prefill_delay_s
+        return False
 
     def preempt(self, seq: Sequence) -> None:
         self._decode_batch = None

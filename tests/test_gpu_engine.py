@@ -249,3 +249,34 @@ def test_single_sequence_prefill_graphs_match_eager_prefill(gpu):
     same = sum(int(a == b) for x, y in zip(eager, graphed) for a, b in zip(x, y))
     total = sum(len(x) for x in eager)
     assert same / total > 0.9, (same, total)
+
+
+def test_serving_loop_in_a_thread_with_graphs_matches_offline(gpu):
+    """The online engine loop builds the engine, captures its hipGraphs and steps it in a
+    background thread; requests that trickle in must produce the tokens of an offline run
+    (sampling noise is keyed by sequence and step, not by batch composition)."""
+    import time
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    from minivllm_amd.serve import AsyncLLMEngine
+    prompts = _prompts(10, seed=11)
+    sp = SamplingParams(temperature=0, max_tokens=24, ignore_eos=True)
+    off = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8]))
+    want = off.generate(prompts, sp)["token_ids"]
+    off.exit()
+    with AsyncLLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8])) as eng:
+        handles = []
+        for i, p in enumerate(prompts):
+            handles.append(eng.submit(p, sp))
+            if i % 3 == 2:
+                time.sleep(0.01)
+        got = [h.result(timeout=120) for h in handles]
+        victim = eng.submit(prompts[0], SamplingParams(temperature=0, max_tokens=400, ignore_eos=True))
+        next(iter(victim))
+        victim.cancel()
+        for _ in victim:
+            pass
+        st = eng.stats()
+    same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
+    total = sum(len(x) for x in want)
+    assert same / total > 0.9, (same, total)        # bf16 batch-shape effects may flip late tokens
+    assert victim.finish_reason == "abort" and st["kv_blocks_free"] == st["kv_blocks"]

@@ -347,3 +347,26 @@ def test_abort_removes_a_request_from_any_queue_and_returns_its_blocks():
     assert sch.abort(a) and sch.is_finished()                 # while decoding
     assert sch.block_manager.num_free_blocks == 16
     assert a.status == SequenceStatus.FINISHED
+
+
+def test_small_prefill_steps_wait_for_company_but_not_forever():
+    import time
+    sch = Scheduler(8, 64, 64, BS, 999, min_prefill_tokens=16, max_prefill_delay_s=0.05)
+    first = seq(range(8), max_tokens=50)
+    sch.add_sequence(first)
+    batch, is_prefill = sch.schedule()                        # nothing is decoding: no reason to wait
+    assert is_prefill and batch == [first]
+    sch.postprocess(batch, [1])
+    late = seq(range(100, 106), max_tokens=4)
+    sch.add_sequence(late)
+    batch, is_prefill = sch.schedule()                        # 6 tokens < 16: keep decoding for now
+    assert not is_prefill and batch == [first] and list(sch.waiting) == [late]
+    sch.postprocess(batch, [2])
+    time.sleep(0.06)
+    batch, is_prefill = sch.schedule()                        # waited long enough
+    assert is_prefill and batch == [late]
+    sch.postprocess(batch, [1])
+    a, b = seq(range(200, 208), max_tokens=4), seq(range(300, 308), max_tokens=4)
+    sch.add_sequence(a); sch.add_sequence(b)
+    batch, is_prefill = sch.schedule()                        # together they reach 16: no wait
+    assert is_prefill and batch == [a, b]
