@@ -45,6 +45,8 @@ def main():
     ap.add_argument("--min-prefill-tokens", type=int, default=0)
     ap.add_argument("--max-prefill-delay-ms", type=float, default=0.0,
                     help="hold a small prefill step this long so that arrivals share it")
+    ap.add_argument("--mixed", action="store_true",
+                    help="running sequences take a decode token inside every prefill step")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -66,6 +68,7 @@ def main():
     cfg = EngineConfig(model=model, max_num_sequences=a.max_seqs,
                        max_num_batched_tokens=a.max_batched_tokens, block_size=a.block_size,
                        eos=-1, min_prefill_tokens=a.min_prefill_tokens,
+                       enable_mixed_batches=a.mixed,
                        max_prefill_delay_ms=a.max_prefill_delay_ms,
                        enforce_eager=a.eager or not on_gpu,
                        max_model_length=int(in_lens.max() + out_lens.max()) + 8,
@@ -104,7 +107,7 @@ def main():
            "preemptions": st["preemptions"],
            "config": {"input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
                       "max_seqs": a.max_seqs, "max_batched_tokens": a.max_batched_tokens,
-                      "min_prefill_tokens": a.min_prefill_tokens,
+                      "min_prefill_tokens": a.min_prefill_tokens, "mixed_batches": a.mixed,
                       "max_prefill_delay_ms": a.max_prefill_delay_ms,
                       "dtype": str(cfg.dtype).replace("torch.", ""), "device": a.device}}
     print(json.dumps(res), flush=True)

@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--block-size", type=int, default=256)
     ap.add_argument("--min-prefill-tokens", type=int, default=0,
                     help="defer prefill steps that would carry fewer prompt tokens (0 = never)")
+    ap.add_argument("--mixed", action="store_true",
+                    help="running sequences take a decode token inside every prefill step")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -62,6 +64,7 @@ def main():
     cfg = EngineConfig(model=model, max_num_sequences=a.max_seqs,
                        max_num_batched_tokens=a.max_batched_tokens, block_size=a.block_size,
                        eos=-1, min_prefill_tokens=a.min_prefill_tokens,
+                       enable_mixed_batches=a.mixed,
                        enforce_eager=a.eager or not on_gpu, max_model_length=longest + 8,
                        dtype=torch.bfloat16 if on_gpu else torch.float32, device=a.device, seed=a.seed)
     eng = LLMEngine(cfg)
@@ -86,7 +89,7 @@ def main():
            "config": {"input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
                       "shared_prefix": a.shared_prefix, "max_seqs": a.max_seqs,
                       "max_batched_tokens": a.max_batched_tokens, "block_size": a.block_size,
-                      "min_prefill_tokens": a.min_prefill_tokens,
+                      "min_prefill_tokens": a.min_prefill_tokens, "mixed_batches": a.mixed,
                       "dtype": str(cfg.dtype).replace("torch.", ""), "device": a.device}}
     eng.exit()
     print(json.dumps(res), flush=True)

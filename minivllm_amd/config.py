@@ -153,6 +153,10 @@ class EngineConfig:
     # step is held for at most this long so that requests arriving close together share one step
     # (0 = only defer while sequence slots, not arrivals, are what limits the step)
     max_prefill_delay_ms: float = 0.0
+    # let the running sequences ride along with every prefill step (one decode row each, behind
+    # the prompt rows) instead of standing still while newcomers are prefetched; the reference
+    # never mixes the two phases (scheduler.py:29-63)
+    enable_mixed_batches: bool = False
     # all-reduce decode-sized tensors with the peer-to-peer kernel (parallel/custom_allreduce.py)
     # instead of RCCL; larger tensors still go to RCCL.  Also switched on by MINIVLLM_CUSTOM_AR=1.
     custom_all_reduce: bool = False

@@ -82,7 +82,8 @@ class LLMEngine:
                                    max_model_length=cfg.max_model_length,
                                    enable_chunked_prefill=cfg.enable_chunked_prefill,
                                    min_prefill_tokens=cfg.min_prefill_tokens,
-                                   max_prefill_delay_s=cfg.max_prefill_delay_ms / 1e3)
+                                   max_prefill_delay_s=cfg.max_prefill_delay_ms / 1e3,
+                                   enable_mixed_batches=cfg.enable_mixed_batches)
         self.tokenizer = load_tokenizer(cfg.model_name_or_path, cfg.model.vocab_size)
         self.stats = EngineStats()
         self._exited = False
@@ -134,11 +135,14 @@ class LLMEngine:
                                    "oldest waiting request")
             return [], 0, False
         self._check_workers()
+        riders = self.scheduler.last_num_decode if is_prefill else 0
         if is_prefill:
-            num_tokens = sum(s.num_scheduled_prefill_tokens for s in seqs)
+            # a mixed step counts its prompt tokens plus one token per riding decode sequence
+            num_tokens = sum(s.num_scheduled_prefill_tokens
+                             for s in seqs[:len(seqs) - riders]) + riders
         else:
             num_tokens = len(seqs)
-        token_ids = self.model_runner.run(seqs, is_prefill)
+        token_ids = self.model_runner.run(seqs, is_prefill, riders)
         finished = self.scheduler.postprocess(seqs, token_ids)
         return ([(s.seq_id, s.completion_token_ids) for s in finished], num_tokens, is_prefill)
 

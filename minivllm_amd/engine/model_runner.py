@@ -53,13 +53,19 @@ class Batch:
     has_prefix: bool = False
     step: int = 0
     tables_unchanged: bool = False      # decode: block tables equal the previous step's
+    # mixed step: the last num_decode_seqs sequences of a prefill-form batch contribute one
+    # decode row each, placed behind the num_prefill_tokens prompt rows
+    num_decode_seqs: int = 0
+    num_prefill_tokens: int = 0
     arrays: Dict[str, np.ndarray] = field(default_factory=dict)
 
     def scalars(self) -> dict:
         return dict(is_prefill=self.is_prefill, num_seqs=self.num_seqs, num_tokens=self.num_tokens,
                     max_seqlen_q=self.max_seqlen_q, max_seqlen_k=self.max_seqlen_k,
                     max_context_len=self.max_context_len, has_prefix=self.has_prefix,
-                    step=self.step, tables_unchanged=self.tables_unchanged)
+                    step=self.step, tables_unchanged=self.tables_unchanged,
+                    num_decode_seqs=self.num_decode_seqs,
+                    num_prefill_tokens=self.num_prefill_tokens)
 
 
 PREFILL_GRAPH_MAX_SEQS = 8        # sequences a graph-replayed prefill step can carry
@@ -392,14 +398,23 @@ class ModelRunner:
             attn.block_size = self.block_size
 
     # ============================================================ batch building
-    def prepare_prefill(self, seqs: Seq[Sequence]) -> Batch:
+    def prepare_prefill(self, seqs: Seq[Sequence], num_decode: int = 0) -> Batch:
+        """``num_decode``: the last that many sequences are running sequences that ride along
+        with one decode token each (mixed step); their row is the newest token, whose key is
+        everything before it in the paged cache."""
         bs = self.block_size
         ids, pos, slots, cu_q, cu_k = [], [], [], [0], [0]
-        max_q = max_k = 0
-        has_prefix = False
-        for seq in seqs:
-            start = seq.num_cached_tokens
-            end = seq.num_tokens if seq.prefill_end is None else seq.prefill_end
+        max_q = max_k = max_ctx = 0
+        has_prefix = num_decode > 0
+        first_decode = len(seqs) - num_decode
+        for i, seq in enumerate(seqs):
+            if i >= first_decode:
+                start, end = seq.num_tokens - 1, seq.num_tokens
+                max_ctx = max(max_ctx, end)
+            else:
+                start = seq.num_cached_tokens
+                end = seq.num_tokens if seq.prefill_end is None else seq.prefill_end
+                max_q = max(max_q, end - start)
             has_prefix |= start > 0
             p = np.arange(start, end, dtype=np.int32)
             bt = np.asarray(seq.block_table, dtype=np.int32)
@@ -408,7 +423,7 @@ class ModelRunner:
             slots.append(bt[p // bs] * bs + p % bs)
             cu_q.append(cu_q[-1] + end - start)
             cu_k.append(cu_k[-1] + end)
-            max_q, max_k = max(max_q, end - start), max(max_k, end)
+            max_k = max(max_k, end)
         B = len(seqs)
         MB = max(len(s.block_table) for s in seqs)
         tables = np.full((B, MB), -1, np.int32)
@@ -417,6 +432,7 @@ class ModelRunner:
         input_ids = np.concatenate(ids)
         positions = np.concatenate(pos)
         slot_mapping = np.concatenate(slots).astype(np.int32)
+        num_prefill_tokens = int(input_ids.size) - num_decode
         pad = prefill_token_bucket(input_ids.size) - input_ids.size if self.on_gpu else 0
         if pad:
             # rows that belong to no sequence: attention and the LM head go by cu_seqlens and
@@ -424,14 +440,17 @@ class ModelRunner:
             input_ids = np.concatenate([input_ids, np.zeros(pad, np.int32)])
             positions = np.concatenate([positions, np.zeros(pad, np.int32)])
             slot_mapping = np.concatenate([slot_mapping, np.full(pad, -1, np.int32)])
+        arrays = dict(input_ids=input_ids, positions=positions, slot_mapping=slot_mapping,
+                      cu_seqlens_q=np.asarray(cu_q, np.int32),
+                      cu_seqlens_k=np.asarray(cu_k, np.int32),
+                      temperatures=np.asarray([s.temperature for s in seqs], np.float32),
+                      block_tables=tables)
+        if num_decode:
+            arrays["context_lens"] = np.asarray([s.num_tokens for s in seqs[first_decode:]], np.int32)
         return Batch(is_prefill=True, num_seqs=B, num_tokens=int(input_ids.size),
                      max_seqlen_q=max_q, max_seqlen_k=max_k, has_prefix=has_prefix,
-                     arrays=dict(input_ids=input_ids, positions=positions,
-                                 slot_mapping=slot_mapping,
-                                 cu_seqlens_q=np.asarray(cu_q, np.int32),
-                                 cu_seqlens_k=np.asarray(cu_k, np.int32),
-                                 temperatures=np.asarray([s.temperature for s in seqs], np.float32),
-                                 block_tables=tables))
+                     max_context_len=max_ctx, num_decode_seqs=num_decode,
+                     num_prefill_tokens=num_prefill_tokens, arrays=arrays)
 
     def prepare_decode(self, seqs: Seq[Sequence]) -> Batch:
         bs = self.block_size
@@ -474,11 +493,12 @@ class ModelRunner:
         return torch.tensor([s.temperature for s in seqs], dtype=torch.float32, device=self.device)
 
     # ================================================================== run
-    def run(self, seqs: Seq[Sequence], is_prefill: bool) -> Optional[List[int]]:
-        """Rank 0 entry point for one step; returns the sampled token per sequence."""
+    def run(self, seqs: Seq[Sequence], is_prefill: bool, num_decode: int = 0) -> Optional[List[int]]:
+        """Rank 0 entry point for one step; returns the sampled token per sequence.
+        ``num_decode`` > 0 (prefill steps only): the last that many sequences decode."""
         if is_prefill:
             self._decode_prev = None
-            batch = self.prepare_prefill(seqs)
+            batch = self.prepare_prefill(seqs, num_decode)
         else:
             batch = self.prepare_decode(seqs)
         self.step_counter += 1
@@ -497,7 +517,8 @@ class ModelRunner:
         layout, off = {}, 0
         for name, n in (("input_ids", T), ("positions", T), ("slot_mapping", T),
                         ("cu_seqlens_q", B + 1), ("cu_seqlens_k", B + 1), ("temperatures", B),
-                        ("misc", 4), ("block_tables", B * MB)):
+                        ("misc", 4), ("context_lens", b.num_decode_seqs),
+                        ("block_tables", B * MB)):
             layout[name] = (off, n)
             off += al(n)
         self._ensure_prefill_buffers(off)
@@ -505,6 +526,8 @@ class ModelRunner:
         for name, (o, n) in layout.items():
             if name == "misc":
                 host[o] = b.step
+            elif n == 0:
+                continue
             elif name == "temperatures":
                 host[o:o + n] = a[name].astype(np.float32).view(np.int32)
             else:
@@ -515,7 +538,8 @@ class ModelRunner:
                     slot_mapping=v("slot_mapping"), cu_seqlens_q=v("cu_seqlens_q"),
                     cu_seqlens_k=v("cu_seqlens_k"),
                     temperatures=v("temperatures").view(torch.float32),
-                    step=v("misc"), block_tables=v("block_tables").view(B, MB))
+                    step=v("misc"), context_lens=v("context_lens"),
+                    block_tables=v("block_tables").view(B, MB))
 
     def _fill_decode_host(self, b: Batch, padded_bs: int) -> None:
         a = b.arrays
@@ -562,7 +586,7 @@ class ModelRunner:
     # -------------------------------------------------------------- execute
     def execute(self, b: Batch, warmup: bool = False) -> Optional[List[int]]:
         if (b.is_prefill and not warmup and b.num_seqs <= PREFILL_GRAPH_MAX_SEQS
-                and b.num_tokens in self.prefill_graphs):
+                and not b.num_decode_seqs and b.num_tokens in self.prefill_graphs):
             tokens = self._replay_prefill_graph(b)
         elif b.is_prefill:
             t = self._upload_prefill(b)
@@ -570,7 +594,10 @@ class ModelRunner:
                         max_seqlen_q=b.max_seqlen_q, max_seqlen_k=b.max_seqlen_k,
                         slot_mapping=None if warmup else t["slot_mapping"],
                         block_tables=None if warmup else t["block_tables"],
-                        positions=t["positions"], num_seqs=b.num_seqs, has_prefix=b.has_prefix)
+                        positions=t["positions"], num_seqs=b.num_seqs, has_prefix=b.has_prefix,
+                        num_decode_seqs=b.num_decode_seqs, num_prefill_tokens=b.num_prefill_tokens,
+                        context_lens=t["context_lens"] if b.num_decode_seqs else None,
+                        max_context_len=b.max_context_len)
             tokens = self._forward_and_sample(t)
         else:
             B = b.num_seqs

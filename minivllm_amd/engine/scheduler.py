@@ -31,7 +31,8 @@ class Scheduler:
     def __init__(self, max_num_sequences: int, max_num_batched_tokens: int,
                  max_cached_blocks: int, block_size: int, eos: int,
                  max_model_length: Optional[int] = None, enable_chunked_prefill: bool = True,
-                 min_prefill_tokens: int = 0, max_prefill_delay_s: float = 0.0):
+                 min_prefill_tokens: int = 0, max_prefill_delay_s: float = 0.0,
+                 enable_mixed_batches: bool = False):
         self.enable_chunked_prefill = enable_chunked_prefill
         # > 0: while sequences are decoding, newcomers are admitted only once this many prompt
         # tokens can go into one prefill step (or everything that waits fits).  The reference
@@ -42,6 +43,12 @@ class Scheduler:
         # min_prefill_tokens is held back until the oldest waiting request is this old, so that
         # requests arriving within the window are prefetched together
         self.max_prefill_delay_s = max_prefill_delay_s
+        # mixed steps: a prefill step also carries one decode token for every sequence that is
+        # already running (they are appended behind the prefill sequences; their count is
+        # ``last_num_decode``), so decoding does not stall while newcomers are prefetched
+        self.enable_mixed_batches = enable_mixed_batches
+        self.last_num_decode = 0
+        self.num_mixed_steps = 0
         # admitted (blocks allocated) but not yet completely prefetched, oldest first
         self.prefilling: Deque[Sequence] = deque()
         self.block_manager = make_block_manager(max_cached_blocks, block_size)
@@ -91,6 +98,9 @@ class Scheduler:
         bm = self.block_manager
 
         budget = self.max_num_batched_tokens
+        self.last_num_decode = 0
+        if self.enable_mixed_batches:                   # leave room for the riders
+            budget = max(budget - len(self.running), min(budget, self.block_size))
         # phase 0: continue sequences whose prefill was cut by an earlier step's budget
         while self.prefilling and len(scheduled) < self.max_num_sequences and num_tokens < budget:
             seq = self.prefilling[0]
@@ -137,6 +147,8 @@ class Scheduler:
             self.running.append(seq)
         if scheduled:
             self._decode_batch = None
+            if self.enable_mixed_batches:
+                self._add_decode_riders(scheduled, num_tokens)
             return scheduled, True
 
         # phase 2: one token for every running sequence, oldest first
@@ -185,6 +197,30 @@ class Scheduler:
         else:
             self._decode_batch = None
         return scheduled, False
+
+    def _add_decode_riders(self, scheduled: List[Sequence], num_tokens: int) -> None:
+        """Append every running sequence that can take its next token without evicting anyone
+        (a sequence that needs a KV block the pool cannot give simply sits this step out)."""
+        bm, bs = self.block_manager, self.block_size
+        fresh = {id(s) for s in scheduled}
+        riders: List[Sequence] = []
+        for seq in self.running:                        # oldest first
+            if id(seq) in fresh:
+                continue
+            if (len(scheduled) + len(riders) >= self.max_num_sequences
+                    or num_tokens + len(riders) >= self.max_num_batched_tokens):
+                break
+            n = seq.num_tokens
+            if len(seq.block_table) * bs < n:           # this token starts a new KV block
+                if not bm.can_append(seq):
+                    continue
+                bm.append(seq)
+            elif n % bs == 0:                           # this token completes a block: publish it
+                bm.append(seq)
+            riders.append(seq)
+        scheduled.extend(riders)
+        self.last_num_decode = len(riders)
+        self.num_mixed_steps += bool(riders)
 
     def _defer_prefill(self) -> bool:
         """Keep decoding instead of starting a prefill step that would carry too few tokens."""

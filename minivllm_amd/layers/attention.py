@@ -77,6 +77,8 @@ class Attention(nn.Module):
         is attached.  Returns [T, Hq*D]."""
         ctx = get_context()
         T = q.shape[0]
+        if ctx.is_prefill and ctx.num_decode_seqs:
+            return self._mixed(q, ctx)
         if ctx.is_prefill:
             if self.k_cache is not None and ctx.block_tables is not None:
                 o = ops.paged_attention_prefill(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q,
@@ -90,4 +92,26 @@ class Attention(nn.Module):
                 raise RuntimeError("decode needs an allocated KV cache")
             o = ops.paged_attention_decode(q, self.k_cache, self.v_cache, ctx.block_tables,
                                            ctx.context_lens, self.scale, ctx.max_context_len)
+        return o.reshape(T, self.num_heads * self.head_dim)
+
+    def _mixed(self, q: torch.Tensor, ctx) -> torch.Tensor:
+        """Prompt rows through the prefill kernel, the decode rows behind them through the
+        decode kernel (a one-row query in the prefill kernel would stream the KV of its
+        sequence once per query head and fill 1 of 128 tile rows), one output buffer."""
+        if self.k_cache is None or ctx.block_tables is None:
+            raise RuntimeError("a mixed prefill + decode step needs an allocated KV cache")
+        T = q.shape[0]
+        Bd = ctx.num_decode_seqs
+        Bp, Tp = ctx.num_seqs - Bd, ctx.num_prefill_tokens
+        o = q.new_empty((T, self.num_heads, self.head_dim))
+        if Bp:
+            ops.paged_attention_prefill(q[:Tp], self.k_cache, self.v_cache,
+                                        ctx.cu_seqlens_q[:Bp + 1], ctx.cu_seqlens_k[:Bp + 1],
+                                        ctx.block_tables[:Bp], self.scale, ctx.max_seqlen_q,
+                                        out=o[:Tp])
+        ops.paged_attention_decode(q[Tp:Tp + Bd], self.k_cache, self.v_cache,
+                                   ctx.block_tables[Bp:], ctx.context_lens, self.scale,
+                                   ctx.max_context_len, out=o[Tp:Tp + Bd])
+        if T > Tp + Bd:
+            o[Tp + Bd:].zero_()                       # padding rows of the token bucket
         return o.reshape(T, self.num_heads * self.head_dim)

@@ -52,21 +52,30 @@ def flash_attention_prefill(q, k, v, cu_seqlens, scale, max_seqlen=None):
     return torch_ref.flash_attention_prefill(q, k, v, cu_seqlens, scale)
 
 
+def _into(out, res):
+    if out is None:
+        return res
+    out.copy_(res)
+    return out
+
+
 def paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k, block_tables, scale,
-                            max_seqlen_q=None):
+                            max_seqlen_q=None, out=None):
+    """``out``: optional [T, Hq, D] destination (a view into a larger buffer is fine)."""
     if _on_gpu(q):
         return _hip().paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k,
-                                              block_tables, scale, max_seqlen_q)
-    return torch_ref.paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k,
-                                             block_tables, scale)
+                                              block_tables, scale, max_seqlen_q, out=out)
+    return _into(out, torch_ref.paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q,
+                                                        cu_seqlens_k, block_tables, scale))
 
 
 def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scale,
-                           max_context_len=None):
+                           max_context_len=None, out=None):
     if _on_gpu(q):
         return _hip().paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens,
-                                             scale, max_context_len)
-    return torch_ref.paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scale)
+                                             scale, max_context_len, out=out)
+    return _into(out, torch_ref.paged_attention_decode(q, k_cache, v_cache, block_tables,
+                                                       context_lens, scale))
 
 
 def linear(x, weight, bias=None):

@@ -240,7 +240,8 @@ def naive_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, cu_seqlen
 def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                             cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
                             block_tables: torch.Tensor, scale: float,
-                            max_seqlen_q: Optional[int] = None) -> torch.Tensor:
+                            max_seqlen_q: Optional[int] = None,
+                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
     T, hq, d = q.shape
     hkv = k_cache.shape[2]
     cq, ck, bt = _i32(cu_seqlens_q), _i32(cu_seqlens_k), _i32(block_tables)
@@ -250,7 +251,9 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
     sb, st, sh = _cache_strides(k_cache)
     assert _cache_strides(v_cache) == (sb, st, sh)
     assert bt.stride(1) == 1
-    out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    if out is None:
+        out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    assert out.shape == (T, hq, d) and out.stride(2) == 1 and out.dtype == q.dtype
     _check(_prefill(q.data_ptr(), qs_t, qs_h, k_cache.data_ptr(), v_cache.data_ptr(), st, sh, sb,
                     out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
                     bt.data_ptr(), bt.stride(0), k_cache.shape[1], scale, cq.numel() - 1, hq, hkv,
@@ -271,7 +274,8 @@ def decode_num_splits(batch: int, num_kv_heads: int, max_context_len: Optional[i
 def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                            block_tables: torch.Tensor, context_lens: torch.Tensor, scale: float,
                            max_context_len: Optional[int] = None,
-                           num_splits: Optional[int] = None) -> torch.Tensor:
+                           num_splits: Optional[int] = None,
+                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
     B, hq, d = q.shape
     hkv = k_cache.shape[2]
     bt, ctx = _i32(block_tables), _i32(context_lens)
@@ -280,7 +284,9 @@ def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torc
     assert _cache_strides(v_cache) == (sb, st, sh)
     assert bt.stride(1) == 1
     ns = num_splits or decode_num_splits(B, hkv, max_context_len)
-    out = torch.empty((B, hq, d), dtype=q.dtype, device=q.device)
+    if out is None:
+        out = torch.empty((B, hq, d), dtype=q.dtype, device=q.device)
+    assert out.shape == (B, hq, d) and out.stride(2) == 1 and out.dtype == q.dtype
     if ns > 1:
         part_acc = torch.empty(B * hq * ns * d, dtype=torch.float32, device=q.device)
         part_ml = torch.empty(B * hq * ns * 2, dtype=torch.float32, device=q.device)

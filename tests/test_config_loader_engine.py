@@ -149,6 +149,36 @@ def test_chunked_prefill_matches_whole_prompt_prefill():
         _engine(max_num_batched_tokens=32, enable_chunked_prefill=False).add_prompt(prompts[0], sp)
 
 
+def test_mixed_prefill_decode_steps_match_separate_phases():
+    """With mixed batches the running sequences take a decode token inside every prefill step
+    (prompt rows through the prefill path, decode rows through the decode path of the same
+    forward); greedy tokens must equal the phase-separated engine's and fewer steps are needed."""
+    rng = np.random.default_rng(21)
+    shared = rng.integers(0, 400, size=16).tolist()
+    prompts = [rng.integers(0, 400, size=n).tolist() for n in (30, 7, 52, 12, 90, 5, 33)] + \
+              [shared + rng.integers(0, 400, size=n).tolist() for n in (9, 20)]
+    sps = [SamplingParams(temperature=0, max_tokens=m, ignore_eos=True)
+           for m in (12, 30, 6, 18, 9, 25, 14, 8, 16)]
+    plain = _engine(max_num_batched_tokens=64)
+    want = plain.generate(prompts, sps)["token_ids"]
+    steps_plain = plain.stats.prefill_steps + plain.stats.decode_steps
+    plain.exit()
+    mixed = _engine(max_num_batched_tokens=64, enable_mixed_batches=True)
+    got = mixed.generate(prompts, sps)["token_ids"]
+    sch = mixed.scheduler
+    assert sch.num_mixed_steps > 0
+    assert mixed.stats.prefill_steps + mixed.stats.decode_steps < steps_plain
+    assert sch.block_manager.num_free_blocks == sch.block_manager.num_blocks
+    mixed.exit()
+    assert got == want
+    # a cache too small for everyone: riders that cannot get a block sit out, preemption in
+    # the decode phase still works, outputs unchanged
+    tight = _engine(max_num_batched_tokens=64, enable_mixed_batches=True, max_cached_blocks=26)
+    got = tight.generate(prompts, sps)["token_ids"]
+    tight.exit()
+    assert got == want
+
+
 def test_engine_api_surface_and_stop_conditions():
     eng = _engine(eos=7)
     s = eng.add_prompt([1, 2, 3], SamplingParams(temperature=0, max_tokens=5))

@@ -280,3 +280,29 @@ def test_serving_loop_in_a_thread_with_graphs_matches_offline(gpu):
     total = sum(len(x) for x in want)
     assert same / total > 0.9, (same, total)        # bf16 batch-shape effects may flip late tokens
     assert victim.finish_reason == "abort" and st["kv_blocks_free"] == st["kv_blocks"]
+
+
+def test_mixed_prefill_decode_steps_on_gpu(gpu):
+    """Mixed steps on the HIP path: prompt rows through the flash prefill kernel, riding decode
+    rows through the paged decode kernel, one forward; tokens match the phase-separated engine
+    up to bf16 batch-shape effects."""
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    prompts = _prompts(24, lo=5, hi=300, seed=13)
+    sp = [SamplingParams(temperature=0, max_tokens=8 + 3 * (i % 7), ignore_eos=True)
+          for i in range(len(prompts))]
+    plain = LLMEngine(_cfg(max_num_batched_tokens=512))
+    want = plain.generate(prompts, sp)["token_ids"]
+    steps = plain.stats.prefill_steps + plain.stats.decode_steps
+    plain.exit()
+    mixed = LLMEngine(_cfg(max_num_batched_tokens=512, enable_mixed_batches=True,
+                           enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8]))
+    got = mixed.generate(prompts, sp)["token_ids"]
+    assert mixed.scheduler.num_mixed_steps > 0
+    assert mixed.stats.prefill_steps + mixed.stats.decode_steps < steps
+    bm = mixed.scheduler.block_manager
+    assert bm.num_free_blocks == bm.num_blocks
+    mixed.exit()
+    assert [len(t) for t in got] == [len(t) for t in want]
+    same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
+    total = sum(len(x) for x in want)
+    assert same / total > 0.9, (same, total)

@@ -370,3 +370,30 @@ def test_small_prefill_steps_wait_for_company_but_not_forever():
     sch.add_sequence(a); sch.add_sequence(b)
     batch, is_prefill = sch.schedule()                        # together they reach 16: no wait
     assert is_prefill and batch == [a, b]
+
+
+def test_mixed_steps_carry_running_sequences_behind_the_prefill_ones():
+    sch = Scheduler(4, 24, 64, BS, 999, enable_mixed_batches=True)
+    a, b = seq(range(6), max_tokens=9), seq(range(50, 57), max_tokens=9)
+    sch.add_sequence(a); sch.add_sequence(b)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == [a, b] and sch.last_num_decode == 0   # nobody is running yet
+    sch.postprocess(batch, [1, 1])
+    c = seq(range(100, 110), max_tokens=9)
+    sch.add_sequence(c)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch == [c, a, b] and sch.last_num_decode == 2
+    assert len(a.block_table) * BS >= a.num_tokens                      # riders got their blocks
+    sch.postprocess(batch, [5, 2, 2])
+    got = (a.completion_token_ids, b.completion_token_ids, c.completion_token_ids)
+    assert got == ([1, 2], [1, 2], [5])
+    batch, is_prefill = sch.schedule()
+    assert not is_prefill and batch == [a, b, c] and sch.last_num_decode == 0
+    sch.postprocess(batch, [3, 3, 6])
+    # the prompt budget shrinks by the number of riders: 24 - 3 = 21 < 22 prompt tokens, so the
+    # newcomer is cut (chunked prefill) and the riders still fit behind its first chunk
+    d = seq(range(200, 222), max_tokens=3)
+    sch.add_sequence(d)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and batch[0] is d and d.prefill_end == 21 and sch.last_num_decode == 3
+    assert sch.num_mixed_steps == 2
