@@ -125,13 +125,14 @@ def _cfg(world, port):
                         world_size=world, master_port=port, max_cached_blocks=24)
 
 
-def _generate(world, port):
+def _generate(world, port, **overrides):
+    import dataclasses
     from minivllm_amd.engine.llm_engine import LLMEngine
-    eng = LLMEngine(_cfg(world, port))
+    eng = LLMEngine(dataclasses.replace(_cfg(world, port), **overrides))
     rng = np.random.default_rng(3)
     prompts = [rng.integers(0, 331, size=n).tolist() for n in (5, 21, 9, 16, 30)]
     out = eng.generate(prompts, SamplingParams(temperature=0, max_tokens=10, ignore_eos=True))
-    stats = (eng.scheduler.num_preemptions, eng.stats.decode_steps)
+    stats = (eng.scheduler.num_preemptions, eng.stats.decode_steps, eng.scheduler.num_mixed_steps)
     eng.exit()
     return out["token_ids"], stats
 
@@ -142,6 +143,9 @@ def test_tp2_gloo_matches_tp1():
     double, stats = _generate(2, port + 1)          # spawns one gloo worker process
     assert double == single
     assert not pg.is_initialized()                  # exit() tore the group down
+    # mixed prefill + decode steps cross the control channel like any other batch
+    mixed, stats = _generate(2, port + 2, enable_mixed_batches=True, max_num_batched_tokens=40)
+    assert mixed == single and stats[2] > 0
 
 
 def test_tp4_gloo_matches_tp1():
