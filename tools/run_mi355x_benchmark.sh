@@ -32,6 +32,7 @@ python benchmark_prefilling.py --json "$OUT/benchmark_prefilling.json" > "$OUT/b
 python benchmark_decoding.py   --json "$OUT/benchmark_decoding.json"   > "$OUT/benchmark_decoding.log" 2>&1
 python benchmark_activation.py --json "$OUT/benchmark_activation.json" > "$OUT/benchmark_activation.log" 2>&1
 python benchmark_throughput.py --json "$OUT/benchmark_throughput.json" > "$OUT/benchmark_throughput.log" 2>&1
+python benchmark_serving.py --rate 32 --mixed --json "$OUT/benchmark_serving.json" > "$OUT/benchmark_serving.log" 2>&1
 python benchmark_models.py --config qwen3-8b --mode all --quick --json "$OUT/benchmark_models.json" \
   > "$OUT/benchmark_models.log" 2>&1
 echo "== end-to-end demo"
