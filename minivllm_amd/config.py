@@ -34,7 +34,9 @@ def parse_dtype(x) -> torch.dtype:
 
 @dataclass
 class ModelConfig:
-    """Qwen3 architecture hyper-parameters (reference keys: model_runner.py:28-43)."""
+    """Decoder hyper-parameters (reference keys: model_runner.py:28-43).  The reference builds
+    Qwen3 only; the same pre-norm GQA + SwiGLU decoder covers Qwen2.5 (QKV bias, no q/k norm)
+    and Llama 3 (neither), which differ in ``qkv_bias`` / ``qk_norm`` / ``rope_scaling``."""
     vocab_size: int = 151936
     hidden_size: int = 1024
     num_heads: int = 16
@@ -50,13 +52,22 @@ class ModelConfig:
     scale: float = 1.0                 # extra multiplier on 1/sqrt(head_dim)
     tie_word_embeddings: bool = True
     name: str = "qwen3-custom"
+    # per-head RMSNorm on q and k before RoPE.  None = the reference's rule: on unless the QKV
+    # projection has a bias (qwen3.py:48,104-106)
+    qk_norm: Optional[bool] = None
+    # HF-style RoPE frequency scaling, e.g. {"rope_type": "llama3", "factor": 8.0, ...}
+    rope_scaling: Optional[Dict[str, Any]] = None
+
+    @property
+    def use_qk_norm(self) -> bool:
+        return (not self.qkv_bias) if self.qk_norm is None else self.qk_norm
 
     def num_parameters(self) -> int:
         h, i, v = self.hidden_size, self.intermediate_size, self.vocab_size
         qkv = h * (self.num_heads + 2 * self.num_kv_heads) * self.head_dim
         o = self.num_heads * self.head_dim * h
         mlp = 3 * h * i
-        per_layer = qkv + o + mlp + 2 * h + 2 * self.head_dim
+        per_layer = qkv + o + mlp + 2 * h + (2 * self.head_dim if self.use_qk_norm else 0)
         emb = v * h * (1 if self.tie_word_embeddings else 2)
         return per_layer * self.num_layers + emb + h
 
@@ -79,6 +90,16 @@ QWEN3_PRESETS: Dict[str, Dict[str, Any]] = {
                       intermediate_size=17408, vocab_size=151936, tie_word_embeddings=False),
     "qwen3-32b": dict(hidden_size=5120, num_layers=64, num_heads=64, num_kv_heads=8, head_dim=128,
                       intermediate_size=25600, vocab_size=151936, tie_word_embeddings=False),
+    # same decoder, other families (public configurations)
+    "llama-3.1-8b": dict(hidden_size=4096, num_layers=32, num_heads=32, num_kv_heads=8, head_dim=128,
+                         intermediate_size=14336, vocab_size=128256, tie_word_embeddings=False,
+                         qk_norm=False, base=500000.0, max_position=131072, rms_norm_epsilon=1e-5,
+                         rope_scaling=dict(rope_type="llama3", factor=8.0, low_freq_factor=1.0,
+                                           high_freq_factor=4.0,
+                                           original_max_position_embeddings=8192)),
+    "qwen2.5-7b": dict(hidden_size=3584, num_layers=28, num_heads=28, num_kv_heads=4, head_dim=128,
+                       intermediate_size=18944, vocab_size=152064, tie_word_embeddings=False,
+                       qkv_bias=True, qk_norm=False, base=1000000.0, max_position=32768),
     # tiny shapes for tests / smoke runs
     "qwen3-tiny": dict(hidden_size=128, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64,
                        intermediate_size=256, vocab_size=512, tie_word_embeddings=True,

@@ -18,7 +18,9 @@ from minivllm_amd.ops import torch_ref
 
 
 class RotaryEmbedding(nn.Module):
-    def __init__(self, head_size: int, rotary_dim: int, max_position: int, base: float):
+    def __init__(self, head_size: int, rotary_dim: int, max_position: int, base: float,
+                 rope_scaling=None):
+        """``rope_scaling``: HF-style dict (``rope_type`` linear / llama3) or None."""
         super().__init__()
         if rotary_dim != head_size:
             raise ValueError("partial rotary is not supported")
@@ -26,7 +28,8 @@ class RotaryEmbedding(nn.Module):
         self.max_position = max_position
         self.base = base
         self.register_buffer("cos_sin_cache",
-                             torch_ref.build_cos_sin_cache(head_size, max_position, base),
+                             torch_ref.build_cos_sin_cache(head_size, max_position, base,
+                                                           rope_scaling=rope_scaling),
                              persistent=False)
 
     def forward(self, positions: torch.Tensor, query: torch.Tensor, key: torch.Tensor):

@@ -38,7 +38,8 @@ from minivllm_amd.utils.context import get_context
 
 class Qwen3Attention(nn.Module):
     def __init__(self, hidden_size: int, num_heads: int, num_kv_heads: int, head_dim: int,
-                 scale: float, rms_norm_epsilon: float, qkv_bias: bool, rope: RotaryEmbedding):
+                 scale: float, rms_norm_epsilon: float, qkv_bias: bool, rope: RotaryEmbedding,
+                 qk_norm: Optional[bool] = None):
         super().__init__()
         tp = pg.tp_size()
         self.total_num_heads = num_heads
@@ -52,8 +53,8 @@ class Qwen3Attention(nn.Module):
         self.qkv_proj = QKVColumnParallelLinear(hidden_size, head_dim, num_heads, num_kv_heads,
                                                 bias=qkv_bias)
         self.o_proj = RowParallelLinear(num_heads * head_dim, hidden_size, bias=False)
-        # Qwen3 applies q/k norms; Qwen2-style checkpoints (qkv_bias=True) do not
-        self.use_qk_norm = not qkv_bias
+        # Qwen3 applies q/k norms; Qwen2-style checkpoints (qkv_bias=True) and Llama do not
+        self.use_qk_norm = (not qkv_bias) if qk_norm is None else qk_norm
         if self.use_qk_norm:
             self.q_norm = RMSNorm(head_dim, rms_norm_epsilon)
             self.k_norm = RMSNorm(head_dim, rms_norm_epsilon)
@@ -96,7 +97,7 @@ class Qwen3DecoderLayer(nn.Module):
         super().__init__()
         self.self_attn = Qwen3Attention(cfg.hidden_size, cfg.num_heads, cfg.num_kv_heads,
                                         cfg.head_dim, cfg.scale, cfg.rms_norm_epsilon,
-                                        cfg.qkv_bias, rope)
+                                        cfg.qkv_bias, rope, cfg.use_qk_norm)
         self.mlp = Qwen3MLP(cfg.hidden_size, cfg.intermediate_size, cfg.ffn_bias)
         self.input_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_epsilon)
         self.post_attention_layernorm = RMSNorm(cfg.hidden_size, cfg.rms_norm_epsilon)
@@ -123,7 +124,8 @@ class Qwen3Model(nn.Module):
     def __init__(self, cfg: ModelConfig):
         super().__init__()
         self.embed_tokens = VocabParallelEmbedding(cfg.vocab_size, cfg.hidden_size)
-        self.rotary_emb = RotaryEmbedding(cfg.head_dim, cfg.head_dim, cfg.max_position, cfg.base)
+        self.rotary_emb = RotaryEmbedding(cfg.head_dim, cfg.head_dim, cfg.max_position, cfg.base,
+                                          cfg.rope_scaling)
         self.layers = nn.ModuleList(Qwen3DecoderLayer(cfg, self.rotary_emb)
                                     for _ in range(cfg.num_layers))
         self.norm = RMSNorm(cfg.hidden_size, cfg.rms_norm_epsilon)
@@ -232,7 +234,7 @@ class RandomCheckpoint:
                 yield p + "self_attn.q_proj.bias", (c.num_heads * c.head_dim,)
                 yield p + "self_attn.k_proj.bias", (c.num_kv_heads * c.head_dim,)
                 yield p + "self_attn.v_proj.bias", (c.num_kv_heads * c.head_dim,)
-            else:
+            if c.use_qk_norm:
                 yield p + "self_attn.q_norm.weight", (c.head_dim,)
                 yield p + "self_attn.k_norm.weight", (c.head_dim,)
             yield p + "mlp.gate_proj.weight", (c.intermediate_size, c.hidden_size)

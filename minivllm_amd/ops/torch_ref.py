@@ -15,6 +15,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import math
+
 import torch
 
 
@@ -41,10 +43,35 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------ rope
+def scaled_inv_freq(inv_freq: torch.Tensor, rope_scaling) -> torch.Tensor:
+    """Frequency rescaling for context extension.  ``linear``: every frequency divided by
+    ``factor``.  ``llama3`` (Llama 3.1+): wavelengths longer than the original context divided
+    by ``factor``, short ones kept, a smooth blend in between."""
+    if not rope_scaling:
+        return inv_freq
+    kind = rope_scaling.get("rope_type", rope_scaling.get("type", "default"))
+    if kind in ("default", None):
+        return inv_freq
+    factor = float(rope_scaling["factor"])
+    if kind == "linear":
+        return inv_freq / factor
+    if kind == "llama3":
+        low = float(rope_scaling.get("low_freq_factor", 1.0))
+        high = float(rope_scaling.get("high_freq_factor", 4.0))
+        old_ctx = float(rope_scaling.get("original_max_position_embeddings", 8192))
+        wavelen = 2 * math.pi / inv_freq
+        smooth = ((old_ctx / wavelen - low) / (high - low)).clamp(0.0, 1.0)
+        blended = (1 - smooth) * inv_freq / factor + smooth * inv_freq
+        out = torch.where(wavelen > old_ctx / low, inv_freq / factor, blended)
+        return torch.where(wavelen < old_ctx / high, inv_freq, out)
+    raise ValueError(f"unsupported rope_scaling type {kind!r} (have: linear, llama3)")
+
+
 def build_cos_sin_cache(head_dim: int, max_position: int, base: float,
-                        device=None) -> torch.Tensor:
+                        device=None, rope_scaling=None) -> torch.Tensor:
     """[max_position, head_dim] fp32 table: cos in the first half, sin in the second."""
     inv_freq = 1.0 / (base ** (torch.arange(0, head_dim, 2, dtype=torch.float64) / head_dim))
+    inv_freq = scaled_inv_freq(inv_freq, rope_scaling)
     t = torch.arange(max_position, dtype=torch.float64)
     freqs = torch.outer(t, inv_freq)
     table = torch.cat([freqs.cos(), freqs.sin()], dim=-1).float()

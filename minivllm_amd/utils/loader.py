@@ -81,18 +81,34 @@ def load_weights_from_checkpoint(model: nn.Module, path: str) -> int:
 
 
 def model_config_from_hf(path: str):
-    """Build a ModelConfig from a HF ``config.json`` (Qwen3 / Qwen2 keys)."""
+    """Build a ModelConfig from a HF ``config.json`` (model_type qwen3, qwen2, llama, mistral:
+    the same decoder with or without QKV bias / per-head q,k norm)."""
     from minivllm_amd.config import ModelConfig
     with open(os.path.join(path, "config.json")) as f:
         c = json.load(f)
     heads = c["num_attention_heads"]
+    kind = c.get("model_type", "qwen3")
+    if kind not in ("qwen3", "qwen2", "llama", "mistral"):
+        raise ValueError(f"unsupported model_type {kind!r} (have: qwen3, qwen2, llama, mistral)")
+    if c.get("sliding_window") and c.get("use_sliding_window", kind == "mistral"):
+        raise ValueError("sliding-window attention is not supported")
+    if kind in ("llama", "mistral") and c.get("attention_bias", False):
+        raise ValueError("attention_bias on the output projection is not supported")
+    # RoPE settings: `rope_theta` + `rope_scaling` (transformers 4 checkpoints) or one
+    # `rope_parameters` dict carrying both (transformers 5)
+    rope = dict(c.get("rope_parameters") or {})
+    theta = rope.pop("rope_theta", c.get("rope_theta", 1e6))
+    scaling = c.get("rope_scaling") or rope or None
+    if scaling and scaling.get("rope_type", scaling.get("type")) in (None, "default"):
+        scaling = None
     return ModelConfig(
+        qk_norm=(kind == "qwen3"), rope_scaling=scaling,
         vocab_size=c["vocab_size"], hidden_size=c["hidden_size"], num_heads=heads,
         num_kv_heads=c.get("num_key_value_heads", heads),
         head_dim=c.get("head_dim", c["hidden_size"] // heads),
         intermediate_size=c["intermediate_size"], num_layers=c["num_hidden_layers"],
         rms_norm_epsilon=c.get("rms_norm_eps", 1e-6),
-        qkv_bias=c.get("attention_bias", False), ffn_bias=False,
-        base=c.get("rope_theta", 1e6), max_position=c.get("max_position_embeddings", 40960),
+        qkv_bias=c.get("attention_bias", kind == "qwen2"), ffn_bias=c.get("mlp_bias", False),
+        base=theta, max_position=c.get("max_position_embeddings", 40960),
         tie_word_embeddings=c.get("tie_word_embeddings", False),
         name=os.path.basename(os.path.normpath(path)))

@@ -34,14 +34,26 @@ def _prompts(n, lo=5, hi=200, vocab=2048, seed=0):
     return [rng.integers(0, vocab, size=int(rng.integers(lo, hi))).tolist() for _ in range(n)]
 
 
-def test_gpu_logits_match_cpu_oracle(gpu):
+_FAMILIES = {
+    "qwen3": {},
+    "llama3": dict(qk_norm=False, rope_scaling=dict(rope_type="llama3", factor=4.0,
+                                                    low_freq_factor=1.0, high_freq_factor=4.0,
+                                                    original_max_position_embeddings=64)),
+    "qwen2": dict(qk_norm=False, qkv_bias=True),
+}
+
+
+@pytest.mark.parametrize("family", list(_FAMILIES))
+def test_gpu_logits_match_cpu_oracle(gpu, family):
     """One prefill + one decode step: HIP bf16 logits vs the torch_ref fp32 model carrying the
-    same (bf16-rounded) weights."""
+    same (bf16-rounded) weights, for each decoder family (q/k norm, QKV bias, RoPE scaling)."""
+    import dataclasses
     from minivllm_amd.engine.model_runner import ModelRunner
     from minivllm_amd.engine.sequence import Sequence
     from minivllm_amd.engine.block_manager import BlockManager
-    g = ModelRunner(_cfg(), 0)
-    c = ModelRunner(_cfg(device="cpu", dtype=torch.float32), 0)
+    model = dataclasses.replace(_cfg().model, **_FAMILIES[family])
+    g = ModelRunner(_cfg(model=model), 0)
+    c = ModelRunner(_cfg(model=model, device="cpu", dtype=torch.float32), 0)
     c.model.load_state_dict({k: v.float().cpu() for k, v in g.model.state_dict().items()})
     captured = {}
     for r, name in ((g, "gpu"), (c, "cpu")):

@@ -99,6 +99,57 @@ def test_engine_greedy_generation_matches_hf_generate():
         assert got == want
 
 
+@pytest.mark.parametrize("family", ["llama", "qwen2"])
+def test_other_decoder_families_match_hf(family, tmp_path):
+    """The same decoder serves Llama 3 (no QKV bias, no q/k norm, llama3 RoPE scaling) and Qwen2.5
+    (QKV bias, no q/k norm): logits against HF transformers with the same weights, and the HF
+    config.json round trip."""
+    import json
+    tr = pytest.importorskip("transformers")
+    from minivllm_amd.utils.loader import model_config_from_hf
+    scaling = dict(rope_type="llama3", factor=4.0, low_freq_factor=1.0, high_freq_factor=4.0,
+                   original_max_position_embeddings=64)
+    common = dict(vocab_size=320, hidden_size=64, intermediate_size=96, num_hidden_layers=2,
+                  num_attention_heads=4, num_key_value_heads=2, max_position_embeddings=256,
+                  rms_norm_eps=1e-5, rope_theta=10000.0, tie_word_embeddings=False,
+                  attn_implementation="eager")
+    if family == "llama":
+        hf_cfg = tr.LlamaConfig(head_dim=16, rope_scaling=scaling, attention_bias=False, **common)
+        hf = tr.LlamaForCausalLM(hf_cfg)
+    else:
+        hf_cfg = tr.Qwen2Config(use_sliding_window=False, **common)
+        hf = tr.Qwen2ForCausalLM(hf_cfg)
+    hf = hf.eval().float()
+    (tmp_path / "config.json").write_text(json.dumps(hf_cfg.to_dict()))
+    cfg = model_config_from_hf(str(tmp_path))
+    assert not cfg.use_qk_norm and cfg.qkv_bias == (family == "qwen2") and cfg.head_dim == 16
+    assert (cfg.rope_scaling is not None) == (family == "llama")
+    torch.manual_seed(0)
+    with torch.no_grad():
+        for n_, p_ in hf.named_parameters():
+            if "norm" in n_:
+                p_.uniform_(0.5, 1.5)
+            elif p_.dim() == 1:                          # biases
+                p_.normal_(0.0, 0.05)
+            else:
+                p_.normal_(0.0, 0.08)
+    ours = Qwen3ForCausalLM(cfg).eval()
+    state = {k: v for k, v in hf.state_dict().items() if "rotary" not in k}
+    assert load_state_dict_into(ours, state) == len(state)
+    lens = [11, 150]                                     # the long one crosses the scaling band
+    ids = torch.randint(0, cfg.vocab_size, (sum(lens),))
+    cu = torch.tensor([0, 11, 161], dtype=torch.int32)
+    pos = torch.cat([torch.arange(n) for n in lens]).int()
+    set_context(True, cu_seqlens_q=cu, cu_seqlens_k=cu, max_seqlen_q=150, max_seqlen_k=150,
+                positions=pos, num_seqs=2)
+    with torch.no_grad():
+        mine = ours.lm_head.local_logits(ours(ids.int(), pos))
+    reset_context()
+    with torch.no_grad():
+        want = torch.stack([hf(ids[s:e][None]).logits[0, -1] for s, e in ((0, 11), (11, 161))])
+    torch.testing.assert_close(mine, want, atol=3e-4, rtol=3e-4)
+
+
 # ------------------------------------------------------------------ layers
 def test_rms_norm_and_fused_add_formula():
     x, r, w = torch.randn(5, 48), torch.randn(5, 48), torch.rand(48) + 0.5
