@@ -280,7 +280,7 @@ class Scheduler:
                     seq.num_cached_tokens = end
                     continue
             seq.append_token(int(token_id))
-            hit_eos = (not seq.ignore_eos) and token_id == self.eos
+            hit_eos = ((not seq.ignore_eos) and token_id == self.eos) or token_id in seq.stop_token_ids
             hit_len = seq.num_completion_tokens >= seq.max_tokens
             hit_ctx = (self.max_model_length is not None
                        and seq.num_tokens >= self.max_model_length)

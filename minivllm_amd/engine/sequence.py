@@ -30,6 +30,7 @@ class Sequence:
     # chunked prefill: the prefill step scheduled now covers tokens [num_cached_tokens,
     # prefill_end); None = up to the end of the sequence
     prefill_end: Optional[int] = None
+    stop_token_ids: frozenset = frozenset()
 
     def __init__(self, token_ids: List[int], sampling_params: Optional[SamplingParams] = None,
                  block_size: Optional[int] = None):
@@ -47,6 +48,7 @@ class Sequence:
         self.temperature = sp.temperature
         self.max_tokens = sp.max_tokens
         self.ignore_eos = sp.ignore_eos
+        self.stop_token_ids = frozenset(sp.stop_token_ids)   # host-side only (never pickled)
         if block_size is not None:
             self.block_size = block_size
 

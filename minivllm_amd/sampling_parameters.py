@@ -5,7 +5,8 @@ Superset of the reference's ``SamplingParams(temperature, max_tokens, ignore_eos
 greedy sampling; here ``temperature == 0`` selects arg-max decoding, which the
 CPU plumbing configuration needs for token-exact comparisons.
 """
-from dataclasses import dataclass
+from dataclasses import dataclass, field
+from typing import List
 
 
 @dataclass
@@ -13,6 +14,9 @@ class SamplingParams:
     temperature: float = 1.0
     max_tokens: int = 64
     ignore_eos: bool = False
+    # generation also ends (the token is kept) on any of these ids, e.g. a chat model's
+    # end-of-turn token next to the engine-wide ``eos``
+    stop_token_ids: List[int] = field(default_factory=list)
 
     def __post_init__(self):
         if self.temperature < 0:

@@ -85,7 +85,8 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
         try:
             return SamplingParams(temperature=float(body.get("temperature", 1.0)),
                                   max_tokens=16 if max_tokens is None else int(max_tokens),
-                                  ignore_eos=bool(body.get("ignore_eos", False)))
+                                  ignore_eos=bool(body.get("ignore_eos", False)),
+                                  stop_token_ids=[int(t) for t in body.get("stop_token_ids") or []])
         except (TypeError, ValueError) as e:
             raise HTTPException(400, str(e))
 

@@ -220,7 +220,8 @@ class AsyncLLMEngine:
             if h is None:
                 continue
             seq = h._seq
-            eos = not seq.ignore_eos and seq.last_token == self.engine.scheduler.eos
+            eos = ((not seq.ignore_eos and seq.last_token == self.engine.scheduler.eos)
+                   or seq.last_token in seq.stop_token_ids)
             self.requests_finished += 1
             h._finish("stop" if eos else "length")
 

@@ -196,6 +196,11 @@ def test_finish_on_max_tokens_and_eos():
     sch.add_sequence(c)
     batch, _ = sch.schedule()
     assert sch.postprocess(batch, [999]) == []                # eos ignored
+    d = seq(range(5), max_tokens=9, ignore_eos=True, stop_token_ids=[42, 43])
+    sch.add_sequence(d)
+    sch.postprocess(sch.schedule()[0], [5, 5])
+    done = sch.postprocess(sch.schedule()[0], [6, 43])        # per-request stop id ends d, kept
+    assert done == [d] and d.completion_token_ids == [5, 43]
 
 
 def test_preemption_is_lifo_and_recomputes():
