@@ -84,6 +84,8 @@ def main():
            "engine_decode_tok_s": round(st["decode_tok_s"], 1),
            "prefill_steps": st["prefill_steps"], "decode_steps": st["decode_steps"],
            "prefill_tokens_computed": st["prefill_tokens"],
+           "prefill_graph_replays": eng.model_runner.prefill_graph_replays,
+           "prefill_graphs": len(eng.model_runner.prefill_graphs),
            "preemptions": eng.scheduler.num_preemptions,
            "prefix_hit_rate": round(bm["prefix_hit_rate"], 3), "kv_blocks": bm["num_blocks"],
            "config": {"input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,

@@ -146,9 +146,17 @@ class EngineConfig:
     dist_backend: str = "auto"         # 'auto' | 'nccl' | 'gloo'
     # decode graphs
     graph_batch_sizes: Optional[list] = None
-    # prefill steps of at most 8 sequences and this many new tokens replay a hipGraph too
-    # (buckets of 64 tokens, at most 1024; 0 = always launch prefill eagerly)
+    # prefill steps of at most prefill_graph_max_seqs sequences and prefill_graph_max_tokens new
+    # tokens replay a hipGraph too (one per token bucket; 0 = always launch prefill eagerly).
+    # Wider limits are accepted (up to 4096 tokens) but measured slower: a captured step sizes
+    # its attention grid for the worst case of its bucket, and from ~1.5k tokens an eager step
+    # is GPU-bound anyway (Qwen3-0.6B, 4000 tokens: 7.5 ms replayed vs 6.0 ms eager)
     prefill_graph_max_tokens: int = 1024
+    prefill_graph_max_seqs: int = 8
+
+    def prefill_graph_limits(self) -> tuple:
+        """(max tokens, max sequences) of a graph-replayed prefill step."""
+        return min(self.prefill_graph_max_tokens, 4096), max(1, self.prefill_graph_max_seqs)
     log_stats: bool = False
     tuned_gemms: bool = True           # load the shipped TunableOp table for library GEMMs
     checkpoint_path: Optional[str] = None

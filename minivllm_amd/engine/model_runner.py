@@ -68,9 +68,6 @@ class Batch:
                     num_prefill_tokens=self.num_prefill_tokens)
 
 
-PREFILL_GRAPH_MAX_SEQS = 8        # sequences a graph-replayed prefill step can carry
-
-
 def _pad_block_tables(tables: List[List[int]]) -> np.ndarray:
     """[B, max blocks] int32, rows padded with -1, without a Python-level loop over rows."""
     n = np.fromiter(map(len, tables), np.int64, len(tables))
@@ -230,14 +227,20 @@ class ModelRunner:
         # behind a cached prefix) replays a hipGraph as decode does: fixed layout, one buffer
         self.prefill_graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
         self._pg_out: Dict[int, torch.Tensor] = {}
-        pg_max = cfg.prefill_graph_max_tokens if self.on_gpu and not cfg.enforce_eager else 0
+        self.prefill_graph_replays = 0
+        pg_max, self.pg_max_seqs = cfg.prefill_graph_limits()
+        if not self.on_gpu or cfg.enforce_eager:
+            pg_max = 0
         pg_max = int(os.environ.get("MINIVLLM_PREFILL_GRAPH_MAX", pg_max))
-        pg_max = min(pg_max, 1024, cfg.max_num_batched_tokens, cfg.max_model_length)
-        self._pg_sizes = list(range(64, pg_max + 1, 64))        # = the prefill token buckets
+        pg_max = min(pg_max, 4096, cfg.max_num_batched_tokens)
+        self.pg_max_seqs = min(self.pg_max_seqs, cfg.max_num_sequences)
+        # = the prefill token buckets up to pg_max
+        self._pg_sizes = sorted({prefill_token_bucket(t) for t in range(64, pg_max + 1, 64)
+                                 if prefill_token_bucket(t) <= pg_max})
         self._pg_off = {}
         if self._pg_sizes:
             tmax, off = self._pg_sizes[-1], 0
-            S = PREFILL_GRAPH_MAX_SEQS
+            S = self.pg_max_seqs
             for name, n in (("input_ids", tmax), ("positions", tmax), ("slot_mapping", tmax),
                             ("cu_seqlens_q", S + 1), ("cu_seqlens_k", S + 1), ("temperatures", S),
                             ("misc", 4), ("block_tables", S * MB)):
@@ -585,7 +588,7 @@ class ModelRunner:
 
     # -------------------------------------------------------------- execute
     def execute(self, b: Batch, warmup: bool = False) -> Optional[List[int]]:
-        if (b.is_prefill and not warmup and b.num_seqs <= PREFILL_GRAPH_MAX_SEQS
+        if (b.is_prefill and not warmup and b.num_seqs <= self.pg_max_seqs
                 and not b.num_decode_seqs and b.num_tokens in self.prefill_graphs):
             tokens = self._replay_prefill_graph(b)
         elif b.is_prefill:
@@ -717,11 +720,11 @@ class ModelRunner:
                     slot_mapping=v("slot_mapping", tb), cu_seqlens_q=v("cu_seqlens_q"),
                     cu_seqlens_k=v("cu_seqlens_k"),
                     temperatures=v("temperatures").view(torch.float32), step=v("misc"),
-                    block_tables=v("block_tables").view(PREFILL_GRAPH_MAX_SEQS,
+                    block_tables=v("block_tables").view(self.pg_max_seqs,
                                                         self.max_blocks_per_seq))
 
     def _capture_prefill_graphs(self) -> None:
-        """One graph per token bucket for a prefill step of up to PREFILL_GRAPH_MAX_SEQS
+        """One graph per token bucket for a prefill step of up to ``pg_max_seqs``
         sequences (any cached prefix: attention goes through the block table and reads the
         lengths from device memory; unused sequence slots have length 0).  An eager prefill
         step costs ~6 ms of host launches however small it is; replayed, a short prompt is
@@ -746,7 +749,7 @@ class ModelRunner:
                 set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
                             max_seqlen_q=tb, max_seqlen_k=self.cfg.max_model_length,
                             slot_mapping=t["slot_mapping"], block_tables=t["block_tables"],
-                            positions=t["positions"], num_seqs=PREFILL_GRAPH_MAX_SEQS,
+                            positions=t["positions"], num_seqs=self.pg_max_seqs,
                             has_prefix=True)
                 out = self._forward_and_sample(t)
                 reset_context()
@@ -762,7 +765,7 @@ class ModelRunner:
 
     def _replay_prefill_graph(self, b: Batch) -> torch.Tensor:
         a = b.arrays
-        tb, B, S = b.num_tokens, b.num_seqs, PREFILL_GRAPH_MAX_SEQS
+        tb, B, S = b.num_tokens, b.num_seqs, self.pg_max_seqs
         MB = self.max_blocks_per_seq
         host = self._pg_host.numpy()
         for name in ("input_ids", "positions", "slot_mapping"):
@@ -785,4 +788,5 @@ class ModelRunner:
         tab[:B, :mb] = a["block_tables"]
         self._pg_dev.copy_(self._pg_host, non_blocking=True)
         self.prefill_graphs[tb].replay()
+        self.prefill_graph_replays += 1
         return self._pg_out[tb][:B]
