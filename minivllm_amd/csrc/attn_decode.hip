@@ -110,8 +110,9 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         for (int i = 0; i < ITER; ++i) {
             const int tok = min(tile * kTile + st_row[i], L - 1);
             const long off = (long)ids[i] * cs_b + (long)(tok & bs_mask) * cs_t + head_off + st_ch[i] * 8;
-            kr[i] = *reinterpret_cast<const u32x4_t*>(k_cache + off);
-            vr[i] = *reinterpret_cast<const u32x4_t*>(v_cache + off);
+            // every KV byte is used once per step: keep it from displacing weights in L2 / MALL
+            kr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(k_cache + off));
+            vr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(v_cache + off));
         }
     };
 
