@@ -123,6 +123,7 @@ class AsyncLLMEngine:
         self._ids = itertools.count()
         self._active: Dict[int, RequestHandle] = {}        # seq_id -> handle (engine thread)
         self._ready = threading.Event()
+        self._stopped = threading.Event()                  # set when the loop has ended
         self._startup_error: Optional[BaseException] = None
         self._thread: Optional[threading.Thread] = None
         self.engine = None
@@ -167,7 +168,12 @@ class AsyncLLMEngine:
         """Queue a request (any thread).  Pass the running event loop to consume the handle with
         ``async for``."""
         h = RequestHandle(next(self._ids), self, loop)
+        if self._stopped.is_set():                         # nobody would ever read the inbox
+            h._finish("error", RuntimeError("the engine loop is not running"))
+            return h
         self._inbox.put(("add", h, prompt, sampling_params))
+        if self._stopped.is_set():                         # lost the race with a dying loop
+            h._finish("error", RuntimeError("the engine loop is not running"))
         return h
 
     def generate(self, prompt, sampling_params: Optional[SamplingParams] = None,
@@ -237,6 +243,7 @@ class AsyncLLMEngine:
             self.engine = LLMEngine(self._config)
         except BaseException as e:
             self._startup_error = e
+            self._stopped.set()
             self._ready.set()
             return
         self._ready.set()
@@ -274,6 +281,7 @@ class AsyncLLMEngine:
                     st.decode_tokens += num_tokens; st.decode_time += dt; st.decode_steps += 1
                 self._publish(finished)
         finally:
+            self._stopped.set()
             for h in list(self._active.values()):
                 self.engine.scheduler.abort(h._seq)
                 h._finish("abort")

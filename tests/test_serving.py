@@ -100,6 +100,9 @@ def test_shutdown_drains_requests_in_flight(offline_tokens):
     hs = [eng.submit(p, sp) for p in _prompts(3)]
     eng.shutdown(drain=True)
     assert [h.result(timeout=1) for h in hs] == offline_tokens[:3]
+    late = eng.submit(_prompts(1)[0], sp)                      # after the loop has ended
+    with pytest.raises(RuntimeError):
+        late.result(timeout=1)
 
 
 def test_http_api(server_engine, offline_tokens):

@@ -39,14 +39,14 @@ for M in (1, 8, 16):
         ws = [torch.randn(N, K, device="cuda", dtype=torch.bfloat16) for _ in range(copies)]
         tl = bench(torch.nn.functional.linear, x, ws)
         line = f"M={M:2d} {name:8s} library {tl*1e6:6.1f} us ({N*K*2/tl/1e12:4.2f} TB/s)  kernel"
-        for waves in (0, 8, 4):
+        for waves in (0, 16, 8, 4):
             hip._lib.mvl_skinny_gemm_force_waves(waves)
             tk = bench(hip.skinny_linear, x, ws)
             line += f"  w{waves or 'auto'} {tk*1e6:6.1f} us ({N*K*2/tk/1e12:4.2f})"
         if name == "gate_up":
             tlf = bench(lambda a, w: hip.silu_and_mul(torch.nn.functional.linear(a, w)), x, ws)
             line += f" | fused SwiGLU: library+act {tlf*1e6:6.1f} us, kernel"
-            for waves in (0, 8, 4):
+            for waves in (0, 16, 8, 4):
                 hip._lib.mvl_skinny_gemm_force_waves(waves)
                 tf = bench(lambda a, w: hip.skinny_linear(a, w, swiglu=True), x, ws)
                 line += f"  w{waves or 'auto'} {tf*1e6:6.1f}"
