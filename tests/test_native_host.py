@@ -116,3 +116,27 @@ def test_engine_outputs_do_not_depend_on_the_allocator(monkeypatch):
     python = run()
     assert (native[1], python[1]) == ("NativeBlockManager", "BlockManager")
     assert native[0] == python[0] and native[2] == python[2]
+
+
+def test_block_manager_under_address_and_ub_sanitizers(tmp_path):
+    """Host code only: the C++ allocator and a randomised scheduler-like workload
+    (tests/native/block_manager_stress.cpp) built with ASan + UBSan, runtimes linked statically."""
+    import os
+    import shutil
+    import subprocess
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "bm_stress")
+    build = subprocess.run(
+        [gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined",
+         "-fno-sanitize-recover=all", "-static-libasan", "-static-libubsan",
+         os.path.join(root, "tests", "native", "block_manager_stress.cpp"),
+         os.path.join(root, "minivllm_amd", "csrc", "host", "block_manager.cpp"), "-o", exe],
+        capture_output=True, text=True, timeout=300)
+    if build.returncode != 0:
+        pytest.skip("sanitizer runtimes not available: " + build.stderr[-300:])
+    run = subprocess.run([exe, "8000"], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert run.stdout.startswith("ok:")
