@@ -15,7 +15,6 @@ import glob
 import os
 import shutil
 import subprocess
-import sys
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -16,7 +16,7 @@ from __future__ import annotations
 
 import atexit
 import time
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence as Seq, Tuple, Union
 
 import torch.multiprocessing as mp

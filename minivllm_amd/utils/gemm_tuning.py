@@ -12,7 +12,7 @@ table written by a different library version, fall back to the default heuristic
 from __future__ import annotations
 
 import os
-from typing import Iterable, List, Optional, Tuple
+from typing import List, Optional, Tuple
 
 DEFAULT_TABLE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                              "tuned", "tunableop_gfx950.csv")

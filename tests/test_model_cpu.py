@@ -1,12 +1,11 @@
 """CPU eager path: layers and the whole Qwen3 model against independent oracles
 (HF transformers' Qwen3 with the same weights; closed-form layer formulas)."""
-import math
 
 import numpy as np
 import pytest
 import torch
 
-from minivllm_amd.config import EngineConfig, ModelConfig, model_preset
+from minivllm_amd.config import EngineConfig, ModelConfig
 from minivllm_amd.models.qwen3 import Qwen3ForCausalLM, RandomCheckpoint
 from minivllm_amd.ops import torch_ref as ref
 from minivllm_amd.sampling_parameters import SamplingParams

@@ -2,7 +2,6 @@
 others run, token streaming, abort, rejection) and the OpenAI-style HTTP front end."""
 import asyncio
 import json
-import threading
 import time
 
 import pytest

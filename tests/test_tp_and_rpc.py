@@ -187,7 +187,6 @@ def test_forced_single_rank_group_runs_the_sharded_path():
 
 # ------------------------------------------- chunk-pipelined row-parallel GEMM
 def _overlap_worker(rank, world, port, q):
-    import torch.distributed as dist
     from minivllm_amd.parallel import group as g
     from minivllm_amd.parallel.overlap import plan_chunks, row_parallel_linear
     g.init_tensor_parallel(rank, world, "gloo", "127.0.0.1", port)

@@ -5,7 +5,6 @@ streams from HBM; everything inside one graph as it would be in the decode step.
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-import torch.nn.functional as F
 from minivllm_amd.utils.gemm_tuning import enable_tuned_gemms
 
 print("tuned table:", enable_tuned_gemms(), flush=True)
