@@ -20,7 +20,7 @@ def _worker(rank, world, port, q):
                               max_bytes=4 << 20)
         assert car.self_test()
         worst = 0.0
-        sizes = [16, 4096, ONE_SHOT_MAX_BYTES // 2, ONE_SHOT_MAX_BYTES // 2 + 16,
+        sizes = [16 * world, 4096, ONE_SHOT_MAX_BYTES // 2, ONE_SHOT_MAX_BYTES // 2 + 8 * world,
                  256 * 4096, 2 << 20]                      # elements; both sides of the switch
         for dtype in (torch.bfloat16, torch.float16):
             for n in sizes:
@@ -104,17 +104,19 @@ def _worker(rank, world, port, q):
         q.put((rank, None, False, False, traceback.format_exc()))
 
 
-def test_two_ranks_on_one_gpu_match_the_sum():
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_ranks_sharing_one_gpu_match_the_sum(world):
+    """2, 4 and 8 ranks (the kernel is instantiated per group size) all on the one GPU."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29400 + os.getpid() % 300
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 29400 + os.getpid() % 300 + 7 * world
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=150) for _ in procs]
+    res = [q.get(timeout=170) for _ in procs]
     for p in procs:
         p.join(timeout=30)
         if p.is_alive():
