@@ -21,7 +21,8 @@ def _worker(rank, world, port, q):
         assert car.self_test()
         worst = 0.0
         sizes = [16 * world, 4096, ONE_SHOT_MAX_BYTES // 2, ONE_SHOT_MAX_BYTES // 2 + 8 * world,
-                 256 * 4096, 2 << 20]                      # elements; both sides of the switch
+                 256 * 4096, 2 << 20,                      # elements; both sides of the switch
+                 5 * 512, 448 * 512, 333 * 1024, 24 * 5120]   # [tokens, hidden] of real steps
         for dtype in (torch.bfloat16, torch.float16):
             for n in sizes:
                 assert n % (8 * world) == 0
