@@ -61,6 +61,21 @@ def decode_message(buf) -> Tuple[str, Dict[str, Any], Dict[str, np.ndarray]]:
     return method, scalars, arrays
 
 
+def _attach_untracked(name: str) -> shared_memory.SharedMemory:
+    """Attach to an existing segment without telling this process's resource tracker about it.
+    Only the creator owns the segment's lifetime: a tracked reader would unlink it when it exits
+    (own tracker, ranks started by a launcher) or make the shared tracker log KeyErrors for the
+    second and later unregistrations (workers spawned by the front end).  Python >= 3.13 has
+    ``track=False`` for this; here registration is switched off for the duration of the call."""
+    from multiprocessing import resource_tracker
+    orig = resource_tracker.register
+    resource_tracker.register = lambda *a, **k: None
+    try:
+        return shared_memory.SharedMemory(name=name)
+    finally:
+        resource_tracker.register = orig
+
+
 class ShmBroadcastChannel:
     def __init__(self, name: str, num_readers: int, create: bool, size: int = 8 << 20,
                  attach_timeout_s: float = 120.0):
@@ -82,14 +97,7 @@ class ShmBroadcastChannel:
             deadline = time.monotonic() + attach_timeout_s
             while True:
                 try:
-                    self.shm = shared_memory.SharedMemory(name=name)
-                    # only the creator owns the segment's lifetime: keep this process's
-                    # resource tracker from unlinking it when a reader exits
-                    try:
-                        from multiprocessing import resource_tracker
-                        resource_tracker.unregister(self.shm._name, "shared_memory")
-                    except Exception:
-                        pass
+                    self.shm = _attach_untracked(name)
                     break
                 except FileNotFoundError:
                     if time.monotonic() > deadline:
