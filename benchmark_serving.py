@@ -105,6 +105,7 @@ def main():
            "ttft_ms": pct(ttft), "tpot_ms": pct(tpot), "e2e_ms": pct(e2e),
            "prefill_steps": st["prefill_steps"], "decode_steps": st["decode_steps"],
            "preemptions": st["preemptions"],
+           "kv_blocks": st["kv_blocks"], "kv_blocks_free_at_end": st["kv_blocks_free"],
            "config": {"input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
                       "max_seqs": a.max_seqs, "max_batched_tokens": a.max_batched_tokens,
                       "min_prefill_tokens": a.min_prefill_tokens, "mixed_batches": a.mixed,
