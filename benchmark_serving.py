@@ -47,6 +47,10 @@ def main():
                     help="hold a small prefill step this long so that arrivals share it")
     ap.add_argument("--mixed", action="store_true",
                     help="running sequences take a decode token inside every prefill step")
+    ap.add_argument("--data-parallel-size", type=int, default=1,
+                    help="engine replicas behind the front end (one GPU each; on a one-GPU box "
+                         "they share it, for rehearsal)")
+    ap.add_argument("--gpu-memory-utilization", type=float, default=0.9)
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -73,8 +77,12 @@ def main():
                        enforce_eager=a.eager or not on_gpu,
                        max_model_length=int(in_lens.max() + out_lens.max()) + 8,
                        dtype=torch.bfloat16 if on_gpu else torch.float32, device=a.device,
-                       seed=a.seed)
-    eng = AsyncLLMEngine(cfg)
+                       gpu_memory_utilization=a.gpu_memory_utilization, seed=a.seed)
+    if a.data_parallel_size > 1:
+        from minivllm_amd.serve import DataParallelAsyncEngine
+        eng = DataParallelAsyncEngine(cfg, a.data_parallel_size)
+    else:
+        eng = AsyncLLMEngine(cfg)
     # one request through the whole path before the clock starts
     eng.generate(prompts[0][:16], SamplingParams(temperature=0.8, max_tokens=4, ignore_eos=True))
 
@@ -107,6 +115,7 @@ def main():
            "preemptions": st["preemptions"],
            "kv_blocks": st["kv_blocks"], "kv_blocks_free_at_end": st["kv_blocks_free"],
            "config": {"input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
+                      "data_parallel_size": a.data_parallel_size,
                       "max_seqs": a.max_seqs, "max_batched_tokens": a.max_batched_tokens,
                       "min_prefill_tokens": a.min_prefill_tokens, "mixed_batches": a.mixed,
                       "max_prefill_delay_ms": a.max_prefill_delay_ms,

@@ -1,7 +1,8 @@
 """OpenAI-style HTTP front end for ``AsyncLLMEngine``.
 
     python -m minivllm_amd.serve.api_server --model-preset qwen3-8b --port 8000 \\
-           [--checkpoint-path /path/to/Qwen3-8B] [--world-size 8] [--max-num-sequences 1024]
+           [--checkpoint-path /path/to/Qwen3-8B] [--data-parallel-size 8] [--world-size 1] \\
+           [--max-num-sequences 1024] [--mixed-batches]
 
 Endpoints: ``POST /v1/completions`` and ``POST /v1/chat/completions`` (JSON in, JSON or
 server-sent events out with ``"stream": true``), ``GET /v1/models``, ``GET /health``,
@@ -67,7 +68,7 @@ def _metrics():
 def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
     app = FastAPI(title="minivllm_amd")
     registry, m = _metrics()
-    max_len = engine.engine.cfg.max_model_length
+    max_len = engine.cfg.max_model_length
 
     def _account(h: RequestHandle) -> None:
         m["requests"].labels(h.finish_reason or "unknown").inc()
@@ -247,6 +248,8 @@ def main(argv: Optional[List[str]] = None) -> None:
     ap.add_argument("--host", default="127.0.0.1")
     ap.add_argument("--port", type=int, default=8000)
     ap.add_argument("--world-size", type=int, default=1, help="tensor-parallel degree")
+    ap.add_argument("--data-parallel-size", type=int, default=1,
+                    help="engine replicas (each on its own --world-size GPUs) behind this server")
     ap.add_argument("--max-num-sequences", type=int, default=256)
     ap.add_argument("--max-num-batched-tokens", type=int, default=16384)
     ap.add_argument("--max-model-length", type=int, default=8192)
@@ -271,7 +274,11 @@ def main(argv: Optional[List[str]] = None) -> None:
     if a.device != "cuda":
         cfg["dtype"] = "float32"
     import uvicorn
-    engine = AsyncLLMEngine(cfg)
+    if a.data_parallel_size > 1:
+        from minivllm_amd.serve.dp_router import DataParallelAsyncEngine
+        engine = DataParallelAsyncEngine(cfg, a.data_parallel_size)
+    else:
+        engine = AsyncLLMEngine(cfg)
     try:
         uvicorn.run(create_app(engine, a.model_preset), host=a.host, port=a.port, log_level="info")
     finally:

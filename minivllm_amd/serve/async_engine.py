@@ -31,12 +31,17 @@ class RequestHandle:
     step that produced tokens for it) and then stops; ``finish_reason`` is ``"stop"`` (EOS),
     ``"length"`` (``max_tokens`` or the context limit), ``"abort"`` or ``"error"``."""
 
-    def __init__(self, request_id: int, owner: "AsyncLLMEngine",
-                 loop: Optional[asyncio.AbstractEventLoop] = None):
+    def __init__(self, request_id: int, owner, loop: Optional[asyncio.AbstractEventLoop] = None,
+                 sink=None):
+        """``owner`` implements ``_cancel(handle)``.  ``sink(handle, tokens_or_None)``, when
+        given, receives every item instead of a queue (None = finished); it is called on the
+        producing thread and must not block."""
         self.request_id = request_id
         self._owner = owner
         self._loop = loop
-        self._q = asyncio.Queue() if loop is not None else queue.Queue()
+        self._sink = sink
+        self._q = None if sink is not None else (asyncio.Queue() if loop is not None
+                                                 else queue.Queue())
         self.token_ids: List[int] = []           # everything generated so far
         self.num_prompt_tokens = 0
         self.finish_reason: Optional[str] = None
@@ -51,7 +56,9 @@ class RequestHandle:
 
     # ------------------------------------------------ engine thread side
     def _put(self, item) -> None:
-        if self._loop is not None:
+        if self._sink is not None:
+            self._sink(self, None if item is _DONE else item)
+        elif self._loop is not None:
             try:
                 self._loop.call_soon_threadsafe(self._q.put_nowait, item)
             except RuntimeError:                  # the consumer's loop is gone
@@ -81,7 +88,7 @@ class RequestHandle:
     def cancel(self) -> None:
         """Ask the engine to drop the request (no-op once it has finished)."""
         if not self.finished:
-            self._owner._inbox.put(("abort", self))
+            self._owner._cancel(self)
 
     def __iter__(self):
         assert self._loop is None, "created for asyncio: use 'async for'"
@@ -163,11 +170,21 @@ class AsyncLLMEngine:
         return self.engine.tokenizer
 
     # ------------------------------------------------------------ requests
+    @property
+    def cfg(self):
+        return self.engine.cfg
+
+    def _cancel(self, handle: RequestHandle) -> None:
+        self._inbox.put(("abort", handle))
+
     def submit(self, prompt: Union[str, Seq[int]], sampling_params: Optional[SamplingParams] = None,
-               loop: Optional[asyncio.AbstractEventLoop] = None) -> RequestHandle:
+               loop: Optional[asyncio.AbstractEventLoop] = None, sink=None) -> RequestHandle:
         """Queue a request (any thread).  Pass the running event loop to consume the handle with
-        ``async for``."""
-        h = RequestHandle(next(self._ids), self, loop)
+        ``async for``, or a ``sink`` callable to be called with every item (see RequestHandle)."""
+        h = RequestHandle(next(self._ids), self, loop, sink)
+        return self._submit_handle(h, prompt, sampling_params)
+
+    def _submit_handle(self, h: RequestHandle, prompt, sampling_params) -> RequestHandle:
         if self._stopped.is_set():                         # nobody would ever read the inbox
             h._finish("error", RuntimeError("the engine loop is not running"))
             return h

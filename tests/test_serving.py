@@ -150,3 +150,43 @@ def test_http_api(server_engine, offline_tokens):
     text = client.get("/metrics").text
     assert 'minivllm_requests_total{finish_reason="length"}' in text
     assert "minivllm_generated_tokens_total" in text and "minivllm_kv_blocks_free" in text
+
+
+def test_two_replicas_behind_one_front_end(offline_tokens):
+    """Data-parallel online serving: two replica processes (CPU here), requests routed by
+    outstanding tokens, streamed back through one queue; same tokens as the offline engine."""
+    from fastapi.testclient import TestClient
+    from minivllm_amd.serve import DataParallelAsyncEngine
+    from minivllm_amd.serve.api_server import create_app
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    with DataParallelAsyncEngine(dict(CFG, master_port=29880), 2) as eng:
+        handles = [eng.submit(p, sp) for p in _prompts(6)]
+        assert [h.result(timeout=180) for h in handles] == offline_tokens
+        assert all(h.finish_reason == "length" for h in handles)
+        st = eng.stats()
+        assert len(st["replicas"]) == 2 and st["requests_finished"] == 6
+        assert all(r["requests_finished"] > 0 for r in st["replicas"])      # both were used
+        assert st["outstanding_tokens"] == [0, 0]
+        # streaming + abort through the router
+        victim = eng.submit(_prompts(1)[0], SamplingParams(temperature=0, max_tokens=80, ignore_eos=True))
+        it = iter(victim)
+        next(it)
+        victim.cancel()
+        for _ in it:
+            pass
+        assert victim.finish_reason == "abort"
+        bad = eng.submit(list(range(1, 90)), SamplingParams(max_tokens=64))
+        with pytest.raises(ValueError):
+            bad.result(timeout=60)
+        # the HTTP front end runs on the router unchanged
+        client = TestClient(create_app(eng, "tiny-dp2"))
+        r = client.post("/v1/completions", json={"prompt": _prompts(2), "max_tokens": 10,
+                                                 "temperature": 0, "ignore_eos": True})
+        assert r.status_code == 200, r.text
+        assert [c["token_ids"] for c in r.json()["choices"]] == offline_tokens[:2]
+        assert "minivllm_kv_blocks_free" in client.get("/metrics").text
+        st = eng.stats()
+        assert st["kv_blocks_free"] == st["kv_blocks"] and st["requests_aborted"] == 1
+    late = eng.submit(_prompts(1)[0], sp)
+    with pytest.raises(RuntimeError):
+        late.result(timeout=1)
