@@ -51,6 +51,8 @@ def main():
                     help="engine replicas behind the front end (one GPU each; on a one-GPU box "
                          "they share it, for rehearsal)")
     ap.add_argument("--gpu-memory-utilization", type=float, default=0.9)
+    ap.add_argument("--kv-blocks", type=int, default=None,
+                    help="cap the KV blocks per engine (replicas sharing one GPU: equal shares)")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--eager", action="store_true")
     ap.add_argument("--seed", type=int, default=0)
@@ -77,7 +79,8 @@ def main():
                        enforce_eager=a.eager or not on_gpu,
                        max_model_length=int(in_lens.max() + out_lens.max()) + 8,
                        dtype=torch.bfloat16 if on_gpu else torch.float32, device=a.device,
-                       gpu_memory_utilization=a.gpu_memory_utilization, seed=a.seed)
+                       gpu_memory_utilization=a.gpu_memory_utilization,
+                       max_cached_blocks=a.kv_blocks, seed=a.seed)
     if a.data_parallel_size > 1:
         from minivllm_amd.serve import DataParallelAsyncEngine
         eng = DataParallelAsyncEngine(cfg, a.data_parallel_size)
