@@ -126,6 +126,15 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
                 else:
                     h.cancel()
 
+    async def _body(request: Request) -> dict:
+        try:
+            body = await request.json()
+        except Exception:
+            raise HTTPException(400, "request body is not valid JSON")
+        if not isinstance(body, dict):
+            raise HTTPException(400, "request body must be a JSON object")
+        return body
+
     def _sse(obj) -> bytes:
         return f"data: {json.dumps(obj)}\n\n".encode()
 
@@ -182,7 +191,7 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
 
     @app.post("/v1/completions")
     async def completions(request: Request):
-        body = await request.json()
+        body = await _body(request)
         sp, prompts = _params(body), _prompts(body.get("prompt"))
         loop = asyncio.get_running_loop()
         rid, created = f"cmpl-{uuid.uuid4().hex}", int(time.time())
@@ -205,7 +214,7 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
 
     @app.post("/v1/chat/completions")
     async def chat(request: Request):
-        body = await request.json()
+        body = await _body(request)
         msgs = body.get("messages")
         if not isinstance(msgs, list) or not msgs:
             raise HTTPException(400, "messages must be a non-empty list")

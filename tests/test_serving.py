@@ -144,6 +144,8 @@ def test_http_api(server_engine, offline_tokens):
     assert msg["message"]["role"] == "assistant" and r.json()["usage"]["completion_tokens"] <= 4
     # bad requests are refused with 400 and the server keeps going
     assert client.post("/v1/completions", json={"prompt": 5}).status_code == 400
+    assert client.post("/v1/completions", content=b"{not json").status_code == 400
+    assert client.post("/v1/chat/completions", json=[1, 2]).status_code == 400
     assert client.post("/v1/completions", json={"prompt": "x", "max_tokens": 0}).status_code == 400
     assert client.post("/v1/completions",
                        json={"prompt": list(range(1, 95)), "max_tokens": 50}).status_code == 400
