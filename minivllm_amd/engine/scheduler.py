@@ -16,6 +16,12 @@ admitted in a prefill step may receive only the tokens the step's budget still h
 for; it then waits in ``prefilling`` and later prefill steps continue it, attending to its
 own earlier chunks through the paged cache, before anything new is admitted.  Only the chunk
 that reaches the end of the sequence yields a sampled token.
+
+Also beyond the reference, all optional: ``min_prefill_tokens`` / ``max_prefill_delay_s`` hold a
+small prefill step back while sequences are decoding (until enough prompt tokens wait, or the
+oldest waiter is that old), ``enable_mixed_batches`` lets every running sequence ride along in a
+prefill step with one decode token (``last_num_decode`` trailing entries of the scheduled list),
+and ``abort`` removes a request from whichever queue holds it.
 """
 from __future__ import annotations
 

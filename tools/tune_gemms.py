@@ -61,6 +61,7 @@ def main():
                     x = torch.randn(M, K, device="cuda", dtype=torch.bfloat16)
                     torch.nn.functional.linear(x, w)
                     torch.cuda.synchronize()
+                    print(f"[{time.time() - t0:7.1f}s]   {gname} M={M}", flush=True)
                 print(f"[{time.time() - t0:7.1f}s] {name} tp{tp} {gname} N={N} K={K}: "
                       f"{len(ms)} M values", flush=True)
                 del w
