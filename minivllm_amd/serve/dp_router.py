@@ -104,6 +104,7 @@ class DataParallelAsyncEngine:
         self._stats_wait: Dict[int, list] = {}
         self._stats_ids = itertools.count()
         self._stopped = threading.Event()
+        self._dead: set = set()                      # replicas whose process has gone away
         self.kv_blocks = [0] * self.dp_size
         ready = 0
         while ready < self.dp_size:
@@ -141,7 +142,11 @@ class DataParallelAsyncEngine:
         sp = sampling_params or SamplingParams()
         cost = len(ids) + sp.max_tokens
         with self._lock:
-            r = min(range(self.dp_size), key=lambda q: (self._load[q], q))
+            alive = [q for q in range(self.dp_size) if q not in self._dead]
+            if not alive:
+                h._finish("error", RuntimeError("no data-parallel replica is alive"))
+                return h
+            r = min(alive, key=lambda q: (self._load[q], q))
             self._load[r] += cost
             self._handles[h.request_id] = h
             self._where[h.request_id] = r
@@ -210,6 +215,24 @@ class DataParallelAsyncEngine:
             if p.is_alive():
                 p.terminate()                        # this replica's process, by handle
 
+    def _reap_dead_replicas(self) -> None:
+        """A replica process that went away takes its requests with it: fail them (the caller
+        can retry) and stop routing to it."""
+        for r, p in enumerate(self._procs):
+            if r in self._dead or p.is_alive():
+                continue
+            with self._lock:
+                self._dead.add(r)
+                lost = [rid for rid, where in self._where.items() if where == r]
+                hs = [self._handles.pop(rid) for rid in lost if rid in self._handles]
+                for rid in lost:
+                    self._where.pop(rid, None)
+                    self._cost.pop(rid, None)
+                self._load[r] = 0
+            err = RuntimeError(f"data-parallel replica {r} (pid {p.pid}) exited with code {p.exitcode}")
+            for h in hs:
+                h._finish("error", err)
+
     def _dispatch(self) -> None:
         stopped = 0
         while stopped < self.dp_size:
@@ -218,7 +241,8 @@ class DataParallelAsyncEngine:
             except queue.Empty:
                 if self._stopped.is_set():
                     break
-                if not any(p.is_alive() for p in self._procs):
+                self._reap_dead_replicas()
+                if len(self._dead) == self.dp_size:
                     break
                 continue
             kind = msg[0]
@@ -246,6 +270,7 @@ class DataParallelAsyncEngine:
                     box.append((msg[1], msg[3]))
             elif kind == "stopped":
                 stopped += 1
+                self._dead.add(msg[1])
         with self._lock:
             left = list(self._handles.values())
             self._handles.clear()

@@ -192,3 +192,19 @@ def test_two_replicas_behind_one_front_end(offline_tokens):
     late = eng.submit(_prompts(1)[0], sp)
     with pytest.raises(RuntimeError):
         late.result(timeout=1)
+
+
+def test_a_dying_replica_fails_its_requests_and_the_other_keeps_serving(offline_tokens):
+    from minivllm_amd.serve import DataParallelAsyncEngine
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    long_sp = SamplingParams(temperature=0, max_tokens=80, ignore_eos=True)
+    with DataParallelAsyncEngine(dict(CFG, master_port=29890), 2) as eng:
+        a = eng.submit(_prompts(1)[0], long_sp)               # replica 0
+        b = eng.submit(_prompts(2)[1], long_sp)               # replica 1
+        next(iter(a)); next(iter(b))                          # both are generating
+        eng._procs[0].terminate()                             # this replica's process, by handle
+        with pytest.raises(RuntimeError):
+            a.result(timeout=60)
+        assert a.finish_reason == "error" and len(b.result(timeout=120)) == 80
+        got = [eng.generate(p, sp, timeout=120) for p in _prompts(3)]   # routed to the survivor
+        assert got == offline_tokens[:3]
