@@ -1,3 +1,6 @@
+"""Prints, per model preset given on the command line, what the start-up measurement of
+``ModelRunner._tune_decode_gemms`` chose per projection and row bucket (library GEMM us, weight-
+streaming kernel us, kernel chosen)."""
 import sys, time, torch
 sys.path.insert(0, '.')
 from minivllm_amd.config import EngineConfig, model_preset

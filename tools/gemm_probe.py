@@ -1,3 +1,5 @@
+"""Library GEMM time and weight bandwidth on the Qwen3-8B projections for M = 1..512 rows
+(default hipBLASLt heuristics, no tuned table): the first look at where decode GEMMs stand."""
 import torch, time
 torch.manual_seed(0)
 shapes = {"qkv": (4096, 6144), "o": (4096, 4096), "gate_up": (4096, 24576), "down": (12288, 4096)}
