@@ -227,6 +227,9 @@ class ModelRunner:
         # behind a cached prefix) replays a hipGraph as decode does: fixed layout, one buffer
         self.prefill_graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
         self._pg_out: Dict[int, torch.Tensor] = {}
+        self._pg_logits: Dict[int, torch.Tensor] = {}      # static logits of each prefill graph
+        self._graph_logits: Dict[int, torch.Tensor] = {}   # ... and of each decode graph
+        self._last_logits: Optional[torch.Tensor] = None
         self.prefill_graph_replays = 0
         pg_max, self.pg_max_seqs = cfg.prefill_graph_limits()
         if not self.on_gpu or cfg.enforce_eager:
@@ -290,6 +293,7 @@ class ModelRunner:
         self.prefill_graphs.clear()
         self._pg_out = {}
         self._graph_out = {}
+        self._pg_logits, self._graph_logits, self._last_logits = {}, {}, None
         self.graph_pool = None
         for layer in self.model.model.layers:
             layer.self_attn.attn.k_cache = layer.self_attn.attn.v_cache = None
@@ -450,6 +454,7 @@ class ModelRunner:
                       block_tables=tables)
         if num_decode:
             arrays["context_lens"] = np.asarray([s.num_tokens for s in seqs[first_decode:]], np.int32)
+        self._add_filter_arrays(arrays, seqs)
         return Batch(is_prefill=True, num_seqs=B, num_tokens=int(input_ids.size),
                      max_seqlen_q=max_q, max_seqlen_k=max_k, has_prefix=has_prefix,
                      max_context_len=max_ctx, num_decode_seqs=num_decode,
@@ -471,6 +476,8 @@ class ModelRunner:
             arrays = dict(input_ids=np.asarray(self._last_tokens, dtype=np.int32), positions=pos,
                           slot_mapping=blk * bs + pos % bs, context_lens=lens,
                           temperatures=a["temperatures"], block_tables=tables)
+            if "top_k" in a:
+                arrays["top_k"], arrays["top_p"] = a["top_k"], a["top_p"]
             self._decode_prev = (seqs, arrays)
             m = int(lens.max())
             return Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1, max_seqlen_k=m,
@@ -483,9 +490,17 @@ class ModelRunner:
                       positions=pos, slot_mapping=last_block * bs + pos % bs, context_lens=lens,
                       temperatures=np.fromiter((s.temperature for s in seqs), np.float32, B),
                       block_tables=tables)
+        self._add_filter_arrays(arrays, seqs)
         self._decode_prev = (seqs, arrays)
         return Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1,
                      max_seqlen_k=int(lens.max()), max_context_len=int(lens.max()), arrays=arrays)
+
+    @staticmethod
+    def _add_filter_arrays(arrays: dict, seqs: Seq[Sequence]) -> None:
+        """top-k / top-p per sequence, only when some request of the batch uses them."""
+        if any(s.top_k > 0 or s.top_p < 1.0 for s in seqs):
+            arrays["top_k"] = np.asarray([s.top_k for s in seqs], np.int32)
+            arrays["top_p"] = np.asarray([s.top_p for s in seqs], np.float32)
 
     def _arange(self, n: int) -> np.ndarray:
         if self._arange_cache.size < n:
@@ -591,6 +606,7 @@ class ModelRunner:
         if (b.is_prefill and not warmup and b.num_seqs <= self.pg_max_seqs
                 and not b.num_decode_seqs and b.num_tokens in self.prefill_graphs):
             tokens = self._replay_prefill_graph(b)
+            logits = self._pg_logits.get(b.num_tokens)
         elif b.is_prefill:
             t = self._upload_prefill(b)
             set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
@@ -602,6 +618,7 @@ class ModelRunner:
                         context_lens=t["context_lens"] if b.num_decode_seqs else None,
                         max_context_len=b.max_context_len)
             tokens = self._forward_and_sample(t)
+            logits = self._last_logits
         else:
             B = b.num_seqs
             bucket = self._graph_bucket(B)
@@ -611,13 +628,17 @@ class ModelRunner:
             if bucket is not None:
                 self.graphs[bucket].replay()
                 tokens = self._graph_out[bucket][:B]
+                logits = self._graph_logits.get(bucket)
             else:
                 t = self._decode_tensors(B)
                 set_context(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
                             block_tables=t["block_tables"], positions=t["positions"],
                             max_context_len=b.max_context_len, num_seqs=B)
                 tokens = self._forward_and_sample(t)
+                logits = self._last_logits
         reset_context()
+        if not warmup and "top_k" in b.arrays:
+            tokens = self._resample_filtered(b, tokens, logits)
         if warmup or tokens is None or self.rank != 0:
             return None
         out = tokens.tolist()
@@ -642,6 +663,7 @@ class ModelRunner:
             from minivllm_amd.ops import hip
             head = self.model.lm_head
             logits = head.local_logits(hidden)
+            self._last_logits = logits
             vals, idx = hip.sample_local(logits, temperatures, self.cfg.seed, step,
                                          vocab_offset=head.vocab_start,
                                          valid_vocab=head.num_embeddings)
@@ -652,9 +674,47 @@ class ModelRunner:
             best = allp[..., 0].argmax(dim=0)
             return allp[..., 1].gather(0, best[None]).squeeze(0).to(torch.int32)
         logits = self.model.compute_logits(hidden)
+        self._last_logits = logits
         if logits is None:
             return None
         return self.sampler(logits, temperatures)
+
+    def _resample_filtered(self, b: Batch, tokens: Optional[torch.Tensor],
+                           logits: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+        """Rows that ask for top-k / top-p are drawn again from the restricted distribution and
+        overwrite the unrestricted draw (the step's logits are still there: inside a replayed
+        graph they sit in a static buffer).  Runs outside the graphs, only for batches that
+        carry such a request; with sharded logits (GPU tensor parallelism) every rank takes
+        part in gathering the rows concerned."""
+        a = b.arrays
+        B = b.num_seqs
+        need = (a["temperatures"][:B] > 0) & ((a["top_k"][:B] > 0) | (a["top_p"][:B] < 1.0))
+        rows = np.nonzero(need)[0]
+        if rows.size == 0 or logits is None:
+            return tokens
+        dev = logits.device
+        ridx = torch.as_tensor(rows, device=dev)
+        lg = logits[:B].index_select(0, ridx)
+        if self.on_gpu and (self.world_size > 1 or pg.collectives_active()):
+            lg = pg.tp_all_gather(lg, dim=-1)                     # shards in vocabulary order
+        lg = lg[:, :self.cfg.model.vocab_size].float()
+        lg = lg / torch.as_tensor(a["temperatures"][rows], device=dev)[:, None]
+        vals, order = lg.sort(dim=-1, descending=True)
+        k = torch.as_tensor(a["top_k"][rows], device=dev).long()
+        p = torch.as_tensor(a["top_p"][rows], device=dev)
+        rank_of = torch.arange(vals.shape[1], device=dev)[None]
+        drop = (k[:, None] > 0) & (rank_of >= k[:, None])
+        probs = torch.softmax(vals, dim=-1)
+        drop |= (probs.cumsum(-1) - probs) >= p[:, None]          # the first token always stays
+        vals = vals.masked_fill(drop, float("-inf"))
+        gen = torch.Generator(device=dev).manual_seed((self.cfg.seed * 1000003 + b.step) % (1 << 62))
+        u = torch.rand(vals.shape, generator=gen, device=dev).clamp_(1e-10, 1.0 - 1e-7)
+        choice = (vals - torch.log(-torch.log(u))).argmax(dim=-1)
+        picked = order.gather(1, choice[:, None]).squeeze(1)
+        if tokens is None:
+            return None
+        tokens[ridx] = picked.to(tokens.dtype)
+        return tokens
 
     # ================================================================ graphs
     def _capture_graphs_or_fall_back(self) -> None:
@@ -707,6 +767,7 @@ class ModelRunner:
                 self.graph_pool = g.pool()
             self.graphs[bs] = g
             self._graph_out[bs] = out
+            self._graph_logits[bs] = self._last_logits
         torch.cuda.synchronize()
         self._capture_prefill_graphs()
 
@@ -761,6 +822,7 @@ class ModelRunner:
                 out = step()
             self.prefill_graphs[tb] = g
             self._pg_out[tb] = out
+            self._pg_logits[tb] = self._last_logits
         torch.cuda.synchronize()
 
     def _replay_prefill_graph(self, b: Batch) -> torch.Tensor:

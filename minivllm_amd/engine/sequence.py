@@ -31,6 +31,8 @@ class Sequence:
     # prefill_end); None = up to the end of the sequence
     prefill_end: Optional[int] = None
     stop_token_ids: frozenset = frozenset()
+    top_k: int = 0
+    top_p: float = 1.0
 
     def __init__(self, token_ids: List[int], sampling_params: Optional[SamplingParams] = None,
                  block_size: Optional[int] = None):
@@ -49,6 +51,8 @@ class Sequence:
         self.max_tokens = sp.max_tokens
         self.ignore_eos = sp.ignore_eos
         self.stop_token_ids = frozenset(sp.stop_token_ids)   # host-side only (never pickled)
+        # rank 0 puts them into the step's batch arrays; greedy requests ignore both
+        self.top_k, self.top_p = (sp.top_k, sp.top_p) if sp.filtered else (0, 1.0)
         if block_size is not None:
             self.block_size = block_size
 

@@ -87,7 +87,9 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
             return SamplingParams(temperature=float(body.get("temperature", 1.0)),
                                   max_tokens=16 if max_tokens is None else int(max_tokens),
                                   ignore_eos=bool(body.get("ignore_eos", False)),
-                                  stop_token_ids=[int(t) for t in body.get("stop_token_ids") or []])
+                                  stop_token_ids=[int(t) for t in body.get("stop_token_ids") or []],
+                                  top_k=int(body.get("top_k") or 0),
+                                  top_p=float(1.0 if body.get("top_p") is None else body["top_p"]))
         except (TypeError, ValueError) as e:
             raise HTTPException(400, str(e))
 

@@ -216,3 +216,47 @@ def test_compat_package_import_paths():
     from myvllm.engine.sequence import Sequence  # noqa: F401
     from myvllm.engine.model_runner import ModelRunner  # noqa: F401
     assert SP is SamplingParams
+
+
+def test_top_k_and_top_p_restrict_the_draw():
+    """top_k=1 and a tiny top_p both reduce sampling to arg-max whatever the temperature; with
+    top_k=3 every sampled token is among the three most likely of its step, and the batch may
+    mix restricted and unrestricted requests."""
+    rng = np.random.default_rng(31)
+    prompts = [rng.integers(0, 400, size=n).tolist() for n in (12, 30, 7, 19)]
+    greedy = _engine()
+    want = greedy.generate(prompts, SamplingParams(temperature=0, max_tokens=8, ignore_eos=True))
+    greedy.exit()
+    for sp in (SamplingParams(temperature=1.5, top_k=1, max_tokens=8, ignore_eos=True),
+               SamplingParams(temperature=1.5, top_p=1e-6, max_tokens=8, ignore_eos=True)):
+        eng = _engine()
+        assert eng.generate(prompts, sp)["token_ids"] == want["token_ids"]
+        eng.exit()
+    eng = _engine()
+    r = eng.model_runner
+    seen = []
+    orig = r._resample_filtered
+
+    def spy(b, tokens, logits):
+        out = orig(b, tokens, logits)
+        seen.append((b.arrays["top_k"].copy(), logits[:b.num_seqs].detach().clone(), out.clone()))
+        return out
+    r._resample_filtered = spy
+    sps = [SamplingParams(temperature=2.0, top_k=3, max_tokens=12, ignore_eos=True),
+           SamplingParams(temperature=2.0, max_tokens=12, ignore_eos=True),          # unrestricted
+           SamplingParams(temperature=2.0, top_k=3, top_p=0.9, max_tokens=12, ignore_eos=True),
+           SamplingParams(temperature=0, top_k=3, max_tokens=12, ignore_eos=True)]   # greedy: ignored
+    out = eng.generate(prompts, sps)["token_ids"]
+    eng.exit()
+    assert seen and all(len(t) == 12 for t in out)
+    picked_other_than_best = 0
+    for top_k, logits, toks in seen:
+        for i in np.nonzero(top_k > 0)[0]:
+            top3 = logits[i].topk(3).indices.tolist()
+            assert int(toks[i]) in top3
+            picked_other_than_best += int(toks[i]) != top3[0]
+    assert picked_other_than_best > 0                      # it does sample, not just arg-max
+    with pytest.raises(ValueError):
+        SamplingParams(top_p=0.0)
+    with pytest.raises(ValueError):
+        SamplingParams(top_k=-1)

@@ -348,3 +348,27 @@ def test_mixed_prefill_decode_steps_on_gpu(gpu):
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
     assert same / total > 0.9, (same, total)
+
+
+def test_top_k_top_p_on_gpu_with_graphs_and_sharded_logits(gpu):
+    """Restricted sampling reads the step's logits out of the replayed graphs' static buffers;
+    with two TP ranks the rows concerned are gathered over the vocabulary shards.  top_k=1 /
+    tiny top_p must reproduce arg-max decoding at any temperature."""
+    import os
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    prompts = _prompts(6, seed=17)
+    greedy = SamplingParams(temperature=0, max_tokens=16, ignore_eos=True)
+    sps = [SamplingParams(temperature=1.3, top_k=1, max_tokens=16, ignore_eos=True),
+           SamplingParams(temperature=1.3, top_p=1e-6, max_tokens=16, ignore_eos=True)] * 3
+    e = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8]))
+    want = e.generate(prompts, greedy)["token_ids"]
+    got = e.generate(prompts, sps)["token_ids"]
+    assert e.model_runner.prefill_graph_replays > 0 and got == want
+    wide = e.generate(prompts, SamplingParams(temperature=1.3, top_k=50, top_p=0.95, max_tokens=16,
+                                              ignore_eos=True))["token_ids"]
+    assert wide != want and all(len(t) == 16 for t in wide)
+    e.exit()
+    two = LLMEngine(_cfg(world_size=2, dist_backend="gloo", master_port=29450 + os.getpid() % 100,
+                         gpu_memory_utilization=0.3))
+    assert two.generate(prompts, sps)["token_ids"] == two.generate(prompts, greedy)["token_ids"]
+    two.exit()
