@@ -170,6 +170,36 @@ def test_tp4_gloo_matches_tp1():
     assert not pg.is_initialized()
 
 
+def test_tp8_gloo_matches_tp1():
+    """Eight ranks, one query/KV head each: the sharding of a whole MI355X node (control channel
+    with seven readers, eight-way vocabulary split and sampling exchange)."""
+    import dataclasses
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    port = 29100 + os.getpid() % 250
+
+    def run(world, p):
+        base = _cfg(world, p)
+        cfg = dataclasses.replace(base, model=dataclasses.replace(
+            base.model, num_heads=8, num_kv_heads=8, head_dim=16, intermediate_size=128))
+        eng = LLMEngine(cfg)
+        rng = np.random.default_rng(6)
+        prompts = [rng.integers(0, 331, size=n).tolist() for n in (9, 14, 4)]
+        out = eng.generate(prompts, SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+        eng.exit()
+        return out["token_ids"]
+
+    before = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = "1"              # eight CPU ranks on a small machine
+    try:
+        assert run(8, port + 8) == run(1, port)
+    finally:
+        if before is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = before
+    assert not pg.is_initialized()
+
+
 def test_forced_single_rank_group_runs_the_sharded_path():
     """world_size 1 with force_tp_group: collectives go through a real (gloo) group."""
     import dataclasses
