@@ -205,7 +205,8 @@ class AsyncLLMEngine:
                    requests_finished=self.requests_finished, requests_aborted=self.requests_aborted,
                    preemptions=sch.num_preemptions,
                    kv_blocks_free=sch.block_manager.num_free_blocks,
-                   kv_blocks=sch.block_manager.num_blocks)
+                   kv_blocks=sch.block_manager.num_blocks,
+                   prefix_hits=sch.block_manager.num_prefix_hits)
         return out
 
     # ------------------------------------------------------- engine thread

@@ -6,8 +6,10 @@ of ``AsyncLLMEngine`` (``submit`` -> ``RequestHandle``, ``stats``, ``shutdown``)
 end runs on either.  Every replica process hosts its own ``AsyncLLMEngine`` (whole weights on its
 own GPU range, its own scheduler and KV cache: the throughput-optimal MI355X deployment of a model
 that fits 288 GB, no collective on the critical path); a request goes to the replica with the
-fewest outstanding tokens, its tokens come back over one shared result queue and a dispatcher
-thread hands them to the caller's handle.  The reference has neither replicas nor a server
+fewest outstanding tokens - unless another replica has recently served a prompt with the same
+first KV block and is not much busier: its prefix cache probably still holds that prefix (system
+prompts, chat histories), so the request is sent there and skips that part of the prefill.  Tokens
+come back over one shared result queue and a dispatcher thread hands them to the caller's handle.  The reference has neither replicas nor a server
 (reference: src/myvllm/engine/llm_engine.py:13-42).
 """
 from __future__ import annotations
@@ -17,6 +19,7 @@ import itertools
 import queue
 import threading
 import traceback
+from collections import OrderedDict
 from typing import Dict, List, Optional, Sequence as Seq, Union
 
 import torch.multiprocessing as mp
@@ -105,6 +108,13 @@ class DataParallelAsyncEngine:
         self._stats_ids = itertools.count()
         self._stopped = threading.Event()
         self._dead: set = set()                      # replicas whose process has gone away
+        # prefix affinity: hash of a prompt's first KV block -> replica that served it last
+        self._affinity: "OrderedDict[int, int]" = OrderedDict()
+        self._affinity_cap = 65536
+        # follow the affinity only while that replica's backlog exceeds the lightest one's by
+        # less than this many tokens
+        self.affinity_slack_tokens = 4 * cfg.max_num_batched_tokens
+        self.affinity_hits = 0
         self.kv_blocks = [0] * self.dp_size
         ready = 0
         while ready < self.dp_size:
@@ -147,6 +157,17 @@ class DataParallelAsyncEngine:
                 h._finish("error", RuntimeError("no data-parallel replica is alive"))
                 return h
             r = min(alive, key=lambda q: (self._load[q], q))
+            key = self._prefix_key(ids)
+            if key is not None:
+                sticky = self._affinity.get(key)
+                if (sticky is not None and sticky not in self._dead
+                        and self._load[sticky] - self._load[r] <= self.affinity_slack_tokens):
+                    self.affinity_hits += 1
+                    r = sticky
+                self._affinity[key] = r
+                self._affinity.move_to_end(key)
+                if len(self._affinity) > self._affinity_cap:
+                    self._affinity.popitem(last=False)
             self._load[r] += cost
             self._handles[h.request_id] = h
             self._where[h.request_id] = r
@@ -157,6 +178,15 @@ class DataParallelAsyncEngine:
     def generate(self, prompt, sampling_params: Optional[SamplingParams] = None,
                  timeout: Optional[float] = None) -> List[int]:
         return self.submit(prompt, sampling_params).result(timeout)
+
+    def _prefix_key(self, ids: List[int]) -> Optional[int]:
+        """Hash of the first full KV block of the prompt (the unit the replicas' prefix caches
+        work in); None for prompts shorter than a block."""
+        bs = self._cfg.block_size
+        if len(ids) <= bs:
+            return None
+        from minivllm_amd.engine.block_manager import BlockManager
+        return BlockManager.compute_hash(ids[:bs])
 
     def _cancel(self, handle: RequestHandle) -> None:
         with self._lock:

@@ -169,6 +169,15 @@ def test_two_replicas_behind_one_front_end(offline_tokens):
         assert len(st["replicas"]) == 2 and st["requests_finished"] == 6
         assert all(r["requests_finished"] > 0 for r in st["replicas"])      # both were used
         assert st["outstanding_tokens"] == [0, 0]
+        # prompts that share their first KV block follow each other to the same replica, whose
+        # prefix cache then serves that block
+        shared = [(3 * j) % 200 + 1 for j in range(16)]
+        fam = [shared + [(11 * i + j) % 200 + 1 for j in range(4 + i)] for i in range(4)]
+        for p in fam:
+            eng.generate(p, sp, timeout=120)
+        per = eng.stats()["replicas"]
+        hits = [r["prefix_hits"] for r in per]
+        assert sorted(hits) == [0, 3], hits                   # all four went to one replica
         # streaming + abort through the router
         victim = eng.submit(_prompts(1)[0], SamplingParams(temperature=0, max_tokens=80, ignore_eos=True))
         it = iter(victim)
