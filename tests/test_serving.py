@@ -217,3 +217,36 @@ def test_a_dying_replica_fails_its_requests_and_the_other_keeps_serving(offline_
         assert a.finish_reason == "error" and len(b.result(timeout=120)) == 80
         got = [eng.generate(p, sp, timeout=120) for p in _prompts(3)]   # routed to the survivor
         assert got == offline_tokens[:3]
+
+
+def test_concurrent_clients_with_random_cancellations(server_engine):
+    """Several client threads submit and cancel at the same time; every handle must reach a
+    final state and every KV block must come back."""
+    import random
+    import threading
+    results, lock = [], threading.Lock()
+
+    def client(k):
+        rnd = random.Random(k)
+        for j in range(8):
+            p = [(13 * k + 5 * j + t) % 200 + 1 for t in range(rnd.randint(3, 40))]
+            h = server_engine.submit(p, SamplingParams(temperature=0.7, max_tokens=rnd.randint(1, 20),
+                                                       ignore_eos=True))
+            if rnd.random() < 0.3:
+                time.sleep(rnd.random() * 0.01)
+                h.cancel()
+            try:
+                toks = h.result(timeout=120)
+            except Exception as e:                        # only rejections are acceptable here
+                toks = e
+            with lock:
+                results.append((h.finish_reason, toks))
+
+    threads = [threading.Thread(target=client, args=(k,)) for k in range(4)]
+    [t.start() for t in threads]
+    [t.join(180) for t in threads]
+    assert len(results) == 32
+    assert all(r in ("length", "abort") for r, _ in results), results
+    assert any(r == "abort" for r, _ in results) and any(r == "length" for r, _ in results)
+    st = server_engine.stats()
+    assert st["running"] == 0 and st["waiting"] == 0 and st["kv_blocks_free"] == st["kv_blocks"]
