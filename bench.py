@@ -69,7 +69,7 @@ def make_config(args, model_name: str, world: int) -> EngineConfig:
         master_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), master_port=port,
         # MINIVLLM_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal only)
         dist_backend=os.environ.get("MINIVLLM_DIST_BACKEND", "auto"),
-        max_cached_blocks=args.kv_blocks).validate()
+        max_cached_blocks=args.kv_blocks, kv_cache_dtype=args.kv_cache_dtype).validate()
 
 
 class _ReplicaTimer:
@@ -341,6 +341,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="no hipGraph decode")
     ap.add_argument("--layers", type=int, default=0, help="override layer count (debug)")
     ap.add_argument("--kv-blocks", type=int, default=None)
+    ap.add_argument("--kv-cache-dtype", choices=["auto", "fp8"], default="auto",
+                    help="'fp8' stores K/V as e4m3 (not the headline configuration; reported)")
     ap.add_argument("--port", type=int, default=29533)
     ap.add_argument("--no-dp", action="store_true", help="with N > 1, skip the data-parallel phase")
     ap.add_argument("--no-tp", action="store_true", help="with N > 1, skip the tensor-parallel phase")
@@ -376,6 +378,7 @@ def main():
     cfg_common = {"model": args.model, "seq_len": args.seq_len,
                   "prefill_tokens_per_step": args.prefill_tokens, "kv_block_size": args.block_size,
                   "hipgraph_decode": not args.eager,
+                  **({"kv_cache_dtype": args.kv_cache_dtype} if args.kv_cache_dtype != "auto" else {}),
                   **({"layers_override": args.layers} if args.layers else {})}
     metric = f"decode tok/s ({args.model}, engine step); prefill tok/s in prefill_tok_s"
 

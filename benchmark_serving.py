@@ -42,6 +42,7 @@ def main():
     ap.add_argument("--max-seqs", type=int, default=256)
     ap.add_argument("--max-batched-tokens", type=int, default=16384)
     ap.add_argument("--block-size", type=int, default=256)
+    ap.add_argument("--kv-cache-dtype", choices=["auto", "fp8"], default="auto")
     ap.add_argument("--min-prefill-tokens", type=int, default=0)
     ap.add_argument("--max-prefill-delay-ms", type=float, default=0.0,
                     help="hold a small prefill step this long so that arrivals share it")
@@ -71,7 +72,7 @@ def main():
     gaps = rng.exponential(1.0 / a.rate, size=a.requests) if a.rate > 0 else np.zeros(a.requests)
     arrivals = np.cumsum(gaps)
     on_gpu = a.device == "cuda"
-    cfg = EngineConfig(model=model, max_num_sequences=a.max_seqs,
+    cfg = EngineConfig(model=model, max_num_sequences=a.max_seqs, kv_cache_dtype=a.kv_cache_dtype,
                        max_num_batched_tokens=a.max_batched_tokens, block_size=a.block_size,
                        eos=-1, min_prefill_tokens=a.min_prefill_tokens,
                        enable_mixed_batches=a.mixed,
@@ -117,7 +118,7 @@ def main():
            "prefill_steps": st["prefill_steps"], "decode_steps": st["decode_steps"],
            "preemptions": st["preemptions"],
            "kv_blocks": st["kv_blocks"], "kv_blocks_free_at_end": st["kv_blocks_free"],
-           "config": {"input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
+           "config": {"kv_cache_dtype": a.kv_cache_dtype, "input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
                       "data_parallel_size": a.data_parallel_size,
                       "max_seqs": a.max_seqs, "max_batched_tokens": a.max_batched_tokens,
                       "min_prefill_tokens": a.min_prefill_tokens, "mixed_batches": a.mixed,

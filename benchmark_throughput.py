@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--max-seqs", type=int, default=256)
     ap.add_argument("--max-batched-tokens", type=int, default=16384)
     ap.add_argument("--block-size", type=int, default=256)
+    ap.add_argument("--kv-cache-dtype", choices=["auto", "fp8"], default="auto")
     ap.add_argument("--min-prefill-tokens", type=int, default=0,
                     help="defer prefill steps that would carry fewer prompt tokens (0 = never)")
     ap.add_argument("--mixed", action="store_true",
@@ -61,7 +62,7 @@ def main():
     params = [SamplingParams(temperature=0.8, max_tokens=int(n), ignore_eos=True) for n in out_lens]
     longest = a.shared_prefix + int(in_lens.max()) + int(out_lens.max())
     on_gpu = a.device == "cuda"
-    cfg = EngineConfig(model=model, max_num_sequences=a.max_seqs,
+    cfg = EngineConfig(model=model, max_num_sequences=a.max_seqs, kv_cache_dtype=a.kv_cache_dtype,
                        max_num_batched_tokens=a.max_batched_tokens, block_size=a.block_size,
                        eos=-1, min_prefill_tokens=a.min_prefill_tokens,
                        enable_mixed_batches=a.mixed,
@@ -88,7 +89,7 @@ def main():
            "prefill_graphs": len(eng.model_runner.prefill_graphs),
            "preemptions": eng.scheduler.num_preemptions,
            "prefix_hit_rate": round(bm["prefix_hit_rate"], 3), "kv_blocks": bm["num_blocks"],
-           "config": {"input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
+           "config": {"kv_cache_dtype": a.kv_cache_dtype, "input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
                       "shared_prefix": a.shared_prefix, "max_seqs": a.max_seqs,
                       "max_batched_tokens": a.max_batched_tokens, "block_size": a.block_size,
                       "min_prefill_tokens": a.min_prefill_tokens, "mixed_batches": a.mixed,

@@ -186,6 +186,11 @@ class EngineConfig:
     # the prompt rows) instead of standing still while newcomers are prefetched; the reference
     # never mixes the two phases (scheduler.py:29-63)
     enable_mixed_batches: bool = False
+    # "auto": the KV cache holds values of the model dtype.  "fp8": OCP e4m3, one byte per value
+    # (gfx950 converts in hardware): twice the tokens per GB and half the bytes the decode
+    # attention kernel streams, at 3 mantissa bits per cached value.  Off by default: it changes
+    # the numerics of attention.
+    kv_cache_dtype: str = "auto"
     # all-reduce decode-sized tensors with the peer-to-peer kernel (parallel/custom_allreduce.py)
     # instead of RCCL; larger tensors still go to RCCL.  Also switched on by MINIVLLM_CUSTOM_AR=1.
     custom_all_reduce: bool = False
@@ -221,6 +226,8 @@ class EngineConfig:
                 f"max_position={m.max_position}")
         if self.max_num_batched_tokens < 1 or self.max_num_sequences < 1:
             raise ValueError("scheduler budgets must be positive")
+        if self.kv_cache_dtype not in ("auto", "fp8"):
+            raise ValueError("kv_cache_dtype must be 'auto' or 'fp8'")
         if not (0.0 < self.gpu_memory_utilization <= 1.0):
             raise ValueError("gpu_memory_utilization must be in (0, 1]")
         return self

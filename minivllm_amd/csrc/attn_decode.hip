@@ -20,7 +20,11 @@
 //    the token on the accumulator rows, which is already the B-operand layout of
 //    O^T = V^T . P^T, and V^T fragments come from ds_read_b64_tr_b16 (hardware transpose);
 //  * the grid does not depend on context lengths (rows with length 0 exit immediately), so
-//    a launch can be captured in a hipGraph and replayed for any batch content.
+//    a launch can be captured in a hipGraph and replayed for any batch content;
+//  * KV8: the cache holds OCP fp8 (e4m3) instead of 16-bit values.  A tile is then half the
+//    bytes (the kernel is bound by exactly those bytes); the registers -> LDS staging step
+//    widens it to the query's 16-bit type, so the LDS image and both MFMA products are the same
+//    code as for a 16-bit cache.
 #include "common.h"
 
 using namespace mvl;
@@ -32,18 +36,35 @@ namespace {
 constexpr int kTile = 32;          // tokens per wave iteration
 constexpr int kWaves = 4;
 
-template <int CODE, int D>
+// 16 fp8 (e4m3) values -> 16 values of the 16-bit type CODE, as two 16-byte chunks
+template <int CODE>
+__device__ __forceinline__ void widen_fp8x16(u32x4_t v, u32x4_t& lo, u32x4_t& hi) {
+    uint32_t o[8];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        const auto f01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], false);
+        const auto f23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], true);
+        o[2 * w] = pack2<CODE>(f01[0], f01[1]);
+        o[2 * w + 1] = pack2<CODE>(f23[0], f23[1]);
+    }
+    lo = u32x4_t{o[0], o[1], o[2], o[3]};
+    hi = u32x4_t{o[4], o[5], o[6], o[7]};
+}
+
+template <int CODE, int D, bool KV8>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
         const uint16_t* __restrict__ q, long q_stride_b, long q_stride_h,
-        const uint16_t* __restrict__ k_cache, const uint16_t* __restrict__ v_cache,
+        const char* __restrict__ k_cache, const char* __restrict__ v_cache,
         long cs_b, long cs_t, long cs_h, const int* __restrict__ block_tables, int bt_stride,
         const int* __restrict__ context_lens, uint16_t* __restrict__ out, long o_stride_b,
         long o_stride_h, float* __restrict__ part_acc, float* __restrict__ part_ml,
         float scale_log2, int Hq, int Hkv, int bs_log2, int nsplit) {
     using DT = DType<CODE>;
     using vec8 = typename DT::vec8;
-    constexpr int CPR = D / 8;                 // 16-byte chunks per row
-    constexpr int ITER = kTile * CPR / 64;     // staging loads per lane per tile
+    constexpr int CPR = D / 8;                 // 16-byte chunks per row of the LDS image
+    constexpr int EB = KV8 ? 1 : 2;            // bytes per cache element
+    constexpr int GCPR = D * EB / 16;          // 16-byte chunks per row in the cache
+    constexpr int ITER = kTile * GCPR / 64;    // staging loads per lane per tile
     constexpr int KSTEPS = D / 32;
     constexpr int NDB = D / 16;
     constexpr int TILE_BYTES = kTile * D * 2;
@@ -94,8 +115,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
         const int c = i * 64 + lane;
-        st_row[i] = c / CPR;
-        st_ch[i] = c % CPR;
+        st_row[i] = c / GCPR;
+        st_ch[i] = c % GCPR;
     }
 
     auto load_block_ids = [&](int tile, int (&ids)[ITER]) {
@@ -109,7 +130,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
             const int tok = min(tile * kTile + st_row[i], L - 1);
-            const long off = (long)ids[i] * cs_b + (long)(tok & bs_mask) * cs_t + head_off + st_ch[i] * 8;
+            const long off = ((long)ids[i] * cs_b + (long)(tok & bs_mask) * cs_t + head_off) * EB
+                             + st_ch[i] * 16;                      // bytes
             // every KV byte is used once per step: keep it from displacing weights in L2 / MALL
             kr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(k_cache + off));
             vr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(v_cache + off));
@@ -135,9 +157,21 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         // registers -> wave-private LDS image (swizzled); same-wave DS ops stay in order
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
-            const int o = tile_off<CPR>(st_row[i], st_ch[i]);
-            *reinterpret_cast<u32x4_t*>(k_lds + o) = kreg[i];
-            *reinterpret_cast<u32x4_t*>(v_lds + o) = vreg[i];
+            if constexpr (KV8) {
+                u32x4_t lo, hi;
+                const int o0 = tile_off<CPR>(st_row[i], 2 * st_ch[i]);
+                const int o1 = tile_off<CPR>(st_row[i], 2 * st_ch[i] + 1);
+                widen_fp8x16<CODE>(kreg[i], lo, hi);
+                *reinterpret_cast<u32x4_t*>(k_lds + o0) = lo;
+                *reinterpret_cast<u32x4_t*>(k_lds + o1) = hi;
+                widen_fp8x16<CODE>(vreg[i], lo, hi);
+                *reinterpret_cast<u32x4_t*>(v_lds + o0) = lo;
+                *reinterpret_cast<u32x4_t*>(v_lds + o1) = hi;
+            } else {
+                const int o = tile_off<CPR>(st_row[i], st_ch[i]);
+                *reinterpret_cast<u32x4_t*>(k_lds + o) = kreg[i];
+                *reinterpret_cast<u32x4_t*>(v_lds + o) = vreg[i];
+            }
         }
         if (tile + kWaves < t1) {
             issue_loads(tile + kWaves, ids_next, kreg, vreg);
@@ -271,7 +305,7 @@ __global__ void decode_reduce_kernel(const float* __restrict__ part_acc,
     out[b * o_stride_b + head * o_stride_h + d] = DType<CODE>::from_float(l > 0.f ? o / l : 0.f);
 }
 
-template <int CODE, int D>
+template <int CODE, int D, bool KV8>
 int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void* vc, long csb,
                   long cst, long csh, const int* bt, int bt_stride, const int* ctx, void* out,
                   long osb, long osh, float* part_acc, float* part_ml, float scale, int B, int Hq,
@@ -282,8 +316,8 @@ int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void*
     const int ngrp = (G + 15) / 16;
     dim3 grid(nsplit, Hkv * ngrp, B);
     const size_t lds = (size_t)kWaves * 2 * kTile * D * 2;
-    paged_decode_kernel<CODE, D><<<grid, 256, lds, st>>>(
-        (const uint16_t*)q, qsb, qsh, (const uint16_t*)kc, (const uint16_t*)vc, csb, cst, csh, bt,
+    paged_decode_kernel<CODE, D, KV8><<<grid, 256, lds, st>>>(
+        (const uint16_t*)q, qsb, qsh, (const char*)kc, (const char*)vc, csb, cst, csh, bt,
         bt_stride, ctx, (uint16_t*)out, osb, osh, part_acc, part_ml, scale * kLog2e, Hq, Hkv,
         bs_log2, nsplit);
     int rc = MVL_CHECK_LAUNCH();
@@ -295,27 +329,32 @@ int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void*
 
 }  // namespace
 
-// q [B, Hq, D] (strides in elements), caches addressed by (block, token, kv head) strides,
-// block_size a power of two, part_* workspaces needed only when nsplit > 1:
-// part_acc [B*Hq*nsplit*D] fp32, part_ml [B*Hq*nsplit*2] fp32.
+// q [B, Hq, D] (strides in elements), caches addressed by (block, token, kv head) strides in
+// cache elements, block_size a power of two, part_* workspaces needed only when nsplit > 1:
+// part_acc [B*Hq*nsplit*D] fp32, part_ml [B*Hq*nsplit*2] fp32.  kv_fp8 != 0: the caches hold
+// OCP fp8 e4m3 bytes instead of values of the query's dtype.
 extern "C" int mvl_paged_attention_decode(
         const void* q, long q_stride_b, long q_stride_h, const void* k_cache, const void* v_cache,
         long cs_b, long cs_t, long cs_h, const int* block_tables, int bt_stride,
         const int* context_lens, void* out, long o_stride_b, long o_stride_h, float* part_acc,
         float* part_ml, float scale, int B, int Hq, int Hkv, int D, int block_size, int nsplit,
-        int dtype, void* stream) {
+        int dtype, int kv_fp8, void* stream) {
     if (B == 0) return 0;
     if ((D != 64 && D != 128) || Hq % Hkv != 0 || (block_size & (block_size - 1)) || nsplit < 1 ||
         nsplit > 64)
         return -1;
     if (nsplit > 1 && (part_acc == nullptr || part_ml == nullptr)) return -2;
     auto st = (hipStream_t)stream;
-#define MVL_DEC(CODE, DD)                                                                       \
-    return launch_decode<CODE, DD>(q, q_stride_b, q_stride_h, k_cache, v_cache, cs_b, cs_t, cs_h, \
-                                   block_tables, bt_stride, context_lens, out, o_stride_b,     \
-                                   o_stride_h, part_acc, part_ml, scale, B, Hq, Hkv,           \
-                                   block_size, nsplit, st)
-    if (dtype == 0) { if (D == 128) MVL_DEC(0, 128); else MVL_DEC(0, 64); }
-    else            { if (D == 128) MVL_DEC(1, 128); else MVL_DEC(1, 64); }
+#define MVL_DEC(CODE, DD, K8)                                                                   \
+    return launch_decode<CODE, DD, K8>(q, q_stride_b, q_stride_h, k_cache, v_cache, cs_b, cs_t,    \
+                                       cs_h, block_tables, bt_stride, context_lens, out,           \
+                                       o_stride_b, o_stride_h, part_acc, part_ml, scale, B, Hq,    \
+                                       Hkv, block_size, nsplit, st)
+    if (kv_fp8) {
+        if (dtype == 0) { if (D == 128) MVL_DEC(0, 128, true); else MVL_DEC(0, 64, true); }
+        else            { if (D == 128) MVL_DEC(1, 128, true); else MVL_DEC(1, 64, true); }
+    }
+    if (dtype == 0) { if (D == 128) MVL_DEC(0, 128, false); else MVL_DEC(0, 64, false); }
+    else            { if (D == 128) MVL_DEC(1, 128, false); else MVL_DEC(1, 64, false); }
 #undef MVL_DEC
 }

@@ -170,7 +170,15 @@ extern "C" int mvl_silu_and_mul(const void* x, void* out, long rows, int inter, 
 // (i, i + D/2) sit in the same lane.  k (after norm + rotation) and v rows are also
 // scattered to the paged cache at slot_mapping[t] (logical slot = block * block_size +
 // offset; the cache's physical layout is given by strides).
-template <int CODE, int D>
+// four floats -> four OCP fp8 (e4m3) bytes in one word, saturating at the format's +-448
+__device__ __forceinline__ uint32_t pack_fp8x4(float a, float b, float c, float d) {
+    auto sat = [](float x) { return fminf(fmaxf(x, -448.f), 448.f); };
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(sat(a), sat(b), 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(sat(c), sat(d), w, true);
+    return (uint32_t)w;
+}
+
+template <int CODE, int D, bool KV8>
 __global__ void qk_norm_rope_store_kernel(
         uint16_t* qkv, long qkv_stride, const int* __restrict__ positions,
         const float* __restrict__ cos_sin, const uint16_t* __restrict__ qw,
@@ -236,10 +244,18 @@ __global__ void qk_norm_rope_store_kernel(
         if (slot >= 0) {
             const int blk = slot / block_size, off = slot - blk * block_size;
             const int kvh = is_k ? h - Hq : h - Hq - Hkv;
-            uint16_t* dst = (is_k ? k_cache : v_cache) + blk * c_stride_b + off * c_stride_t +
-                            kvh * c_stride_h;
-            *reinterpret_cast<u32x2_t*>(dst + 4 * j) = a;
-            *reinterpret_cast<u32x2_t*>(dst + D / 2 + 4 * j) = b;
+            const long at = blk * c_stride_b + off * c_stride_t + kvh * c_stride_h;
+            if constexpr (KV8) {                 // one byte per element; from the 16-bit values
+                uint8_t* dst = reinterpret_cast<uint8_t*>(is_k ? k_cache : v_cache) + at;
+                unpack2<CODE>(a[0], x1[0], x1[1]); unpack2<CODE>(a[1], x1[2], x1[3]);
+                unpack2<CODE>(b[0], x2[0], x2[1]); unpack2<CODE>(b[1], x2[2], x2[3]);
+                *reinterpret_cast<uint32_t*>(dst + 4 * j) = pack_fp8x4(x1[0], x1[1], x1[2], x1[3]);
+                *reinterpret_cast<uint32_t*>(dst + D / 2 + 4 * j) = pack_fp8x4(x2[0], x2[1], x2[2], x2[3]);
+            } else {
+                uint16_t* dst = (is_k ? k_cache : v_cache) + at;
+                *reinterpret_cast<u32x2_t*>(dst + 4 * j) = a;
+                *reinterpret_cast<u32x2_t*>(dst + D / 2 + 4 * j) = b;
+            }
         }
     }
 }
@@ -249,7 +265,7 @@ extern "C" int mvl_qk_norm_rope_store(void* qkv, long qkv_stride, const int* pos
                                       float eps, long T, int Hq, int Hkv, int D, void* k_cache,
                                       void* v_cache, long c_stride_b, long c_stride_t,
                                       long c_stride_h, int block_size, const int* slot_mapping,
-                                      int dtype, void* stream) {
+                                      int dtype, int kv_fp8, void* stream) {
     if (D != 64 && D != 128) return -1;
     if (T == 0) return 0;
     const long rows = T * (Hq + 2 * Hkv);
@@ -258,14 +274,88 @@ extern "C" int mvl_qk_norm_rope_store(void* qkv, long qkv_stride, const int* pos
     const long waves = (rows + rpw - 1) / rpw;
     const long blocks = (waves + 3) / 4;
     auto st = (hipStream_t)stream;
-#define MVL_LAUNCH_ROPE(CODE, DD)                                                              \
-    qk_norm_rope_store_kernel<CODE, DD><<<(unsigned)blocks, threads, 0, st>>>(                 \
+#define MVL_LAUNCH_ROPE(CODE, DD, K8)                                                          \
+    qk_norm_rope_store_kernel<CODE, DD, K8><<<(unsigned)blocks, threads, 0, st>>>(             \
         (uint16_t*)qkv, qkv_stride, positions, cos_sin, (const uint16_t*)qw,                   \
         (const uint16_t*)kw, eps, Hq, Hkv, (uint16_t*)k_cache, (uint16_t*)v_cache, c_stride_b, \
         c_stride_t, c_stride_h, block_size, slot_mapping, rows)
-    if (dtype == 0) { if (D == 128) MVL_LAUNCH_ROPE(0, 128); else MVL_LAUNCH_ROPE(0, 64); }
-    else            { if (D == 128) MVL_LAUNCH_ROPE(1, 128); else MVL_LAUNCH_ROPE(1, 64); }
+    if (kv_fp8) {
+        if (dtype == 0) { if (D == 128) MVL_LAUNCH_ROPE(0, 128, true); else MVL_LAUNCH_ROPE(0, 64, true); }
+        else            { if (D == 128) MVL_LAUNCH_ROPE(1, 128, true); else MVL_LAUNCH_ROPE(1, 64, true); }
+    } else {
+        if (dtype == 0) { if (D == 128) MVL_LAUNCH_ROPE(0, 128, false); else MVL_LAUNCH_ROPE(0, 64, false); }
+        else            { if (D == 128) MVL_LAUNCH_ROPE(1, 128, false); else MVL_LAUNCH_ROPE(1, 64, false); }
+    }
 #undef MVL_LAUNCH_ROPE
+    return MVL_CHECK_LAUNCH();
+}
+
+// ============================================ fp8 KV cache -> packed 16-bit K/V
+// For prefill steps that attend to cached tokens of an fp8 cache: the keys/values of every
+// sequence of the step (its whole context, through the block table) are widened into packed
+// [sum k_len, Hkv, D] tensors of the query's dtype, which the flash-prefill kernel then reads
+// like freshly projected K/V.  (Prefill is bound by its GEMMs; the decode kernel, which is
+// bound by KV bytes, reads the fp8 cache directly.)  grid = (chunks of the longest context, B),
+// one 16-byte cache chunk (16 elements) per thread.
+template <int CODE>
+__global__ void kv_gather_widen_kernel(const uint8_t* __restrict__ k_cache,
+                                       const uint8_t* __restrict__ v_cache, long cs_b, long cs_t,
+                                       long cs_h, int bs_log2, const int* __restrict__ block_tables,
+                                       int bt_stride, const int* __restrict__ cu_k,
+                                       uint16_t* __restrict__ k_out, uint16_t* __restrict__ v_out,
+                                       int Hkv, int D) {
+    const int b = blockIdx.y;
+    const int k_start = cu_k[b], k_len = cu_k[b + 1] - k_start;
+    const int cpr = D / 16, cpt = Hkv * cpr;              // chunks per row / per token
+    const long total = (long)k_len * cpt;
+    const int* bt = block_tables + (long)b * bt_stride;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int tok = (int)(idx / cpt);
+        const int r = (int)(idx - (long)tok * cpt);
+        const int h = r / cpr, c = r - h * cpr;
+        const long src = (long)bt[tok >> bs_log2] * cs_b + (long)(tok & ((1 << bs_log2) - 1)) * cs_t +
+                         (long)h * cs_h + c * 16;
+        const long dst = ((long)(k_start + tok) * Hkv + h) * D + c * 16;
+#pragma unroll
+        for (int which = 0; which < 2; ++which) {
+            const u32x4_t v = *reinterpret_cast<const u32x4_t*>((which ? v_cache : k_cache) + src);
+            uint32_t o[8];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+                const auto f01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], false);
+                const auto f23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], true);
+                o[2 * w] = pack2<CODE>(f01[0], f01[1]);
+                o[2 * w + 1] = pack2<CODE>(f23[0], f23[1]);
+            }
+            u32x4_t* out = reinterpret_cast<u32x4_t*>((which ? v_out : k_out) + dst);
+            out[0] = u32x4_t{o[0], o[1], o[2], o[3]};
+            out[1] = u32x4_t{o[4], o[5], o[6], o[7]};
+        }
+    }
+}
+
+// k_out / v_out: [cu_k[B], Hkv, D] contiguous.  max_k_len bounds the grid only.
+extern "C" int mvl_kv_gather_widen(const void* k_cache, const void* v_cache, long cs_b, long cs_t,
+                                   long cs_h, int block_size, const int* block_tables,
+                                   int bt_stride, const int* cu_k, void* k_out, void* v_out, int B,
+                                   int Hkv, int D, int max_k_len, int dtype, void* stream) {
+    if (D % 16 != 0 || (block_size & (block_size - 1))) return -1;
+    if (B == 0 || max_k_len == 0) return 0;
+    int bs_log2 = 0;
+    while ((1 << bs_log2) < block_size) ++bs_log2;
+    long per_seq = ((long)max_k_len * Hkv * (D / 16) + 255) / 256;
+    if (per_seq > 4096) per_seq = 4096;
+    dim3 grid((unsigned)per_seq, (unsigned)B);
+    auto st = (hipStream_t)stream;
+    if (dtype == 0)
+        kv_gather_widen_kernel<0><<<grid, 256, 0, st>>>(
+            (const uint8_t*)k_cache, (const uint8_t*)v_cache, cs_b, cs_t, cs_h, bs_log2, block_tables,
+            bt_stride, cu_k, (uint16_t*)k_out, (uint16_t*)v_out, Hkv, D);
+    else
+        kv_gather_widen_kernel<1><<<grid, 256, 0, st>>>(
+            (const uint8_t*)k_cache, (const uint8_t*)v_cache, cs_b, cs_t, cs_h, bs_log2, block_tables,
+            bt_stride, cu_k, (uint16_t*)k_out, (uint16_t*)v_out, Hkv, D);
     return MVL_CHECK_LAUNCH();
 }
 

@@ -57,6 +57,7 @@ class Batch:
     # decode row each, placed behind the num_prefill_tokens prompt rows
     num_decode_seqs: int = 0
     num_prefill_tokens: int = 0
+    num_prefill_k_tokens: int = 0       # sum of the context lengths of the prefill sequences
     arrays: Dict[str, np.ndarray] = field(default_factory=dict)
 
     def scalars(self) -> dict:
@@ -65,7 +66,8 @@ class Batch:
                     max_context_len=self.max_context_len, has_prefix=self.has_prefix,
                     step=self.step, tables_unchanged=self.tables_unchanged,
                     num_decode_seqs=self.num_decode_seqs,
-                    num_prefill_tokens=self.num_prefill_tokens)
+                    num_prefill_tokens=self.num_prefill_tokens,
+                    num_prefill_k_tokens=self.num_prefill_k_tokens)
 
 
 def _pad_block_tables(tables: List[List[int]]) -> np.ndarray:
@@ -119,6 +121,8 @@ class ModelRunner:
         self.on_gpu = self.device.type == "cuda"
         self.dtype = cfg.dtype if self.on_gpu else (cfg.dtype if cfg.dtype != torch.float16
                                                     else torch.float32)
+
+        self.kv_dtype = torch.float8_e4m3fn if cfg.kv_cache_dtype == "fp8" else self.dtype
 
         pg.init_tensor_parallel(rank, cfg.world_size, cfg.dist_backend, cfg.master_addr,
                                 cfg.master_port, self.device, force_group=cfg.force_tp_group)
@@ -360,7 +364,7 @@ class ModelRunner:
     # ================================================================ KV cache
     def kv_block_bytes(self) -> int:
         m = self.cfg.model
-        itemsize = torch.empty((), dtype=self.dtype).element_size()
+        itemsize = torch.empty((), dtype=self.kv_dtype).element_size()
         return (2 * m.num_layers * self.block_size * (m.num_kv_heads // self.world_size)
                 * m.head_dim * itemsize)
 
@@ -397,7 +401,7 @@ class ModelRunner:
         # physical order [2, layer, block, kv_head, token, d]; layers see the logical
         # [block, token, kv_head, d] view of it
         self.kv_cache = torch.zeros(2, m.num_layers, self.num_kv_blocks, hkv, self.block_size,
-                                    m.head_dim, dtype=self.dtype, device=self.device)
+                                    m.head_dim, dtype=self.kv_dtype, device=self.device)
         for i, layer in enumerate(self.model.model.layers):
             attn = layer.self_attn.attn
             attn.k_cache = self.kv_cache[0, i].permute(0, 2, 1, 3)
@@ -457,6 +461,7 @@ class ModelRunner:
         self._add_filter_arrays(arrays, seqs)
         return Batch(is_prefill=True, num_seqs=B, num_tokens=int(input_ids.size),
                      max_seqlen_q=max_q, max_seqlen_k=max_k, has_prefix=has_prefix,
+                     num_prefill_k_tokens=int(cu_k[first_decode]),
                      max_context_len=max_ctx, num_decode_seqs=num_decode,
                      num_prefill_tokens=num_prefill_tokens, arrays=arrays)
 
@@ -616,7 +621,7 @@ class ModelRunner:
                         positions=t["positions"], num_seqs=b.num_seqs, has_prefix=b.has_prefix,
                         num_decode_seqs=b.num_decode_seqs, num_prefill_tokens=b.num_prefill_tokens,
                         context_lens=t["context_lens"] if b.num_decode_seqs else None,
-                        max_context_len=b.max_context_len)
+                        max_context_len=b.max_context_len, total_k_tokens=b.num_prefill_k_tokens)
             tokens = self._forward_and_sample(t)
             logits = self._last_logits
         else:

@@ -80,10 +80,15 @@ class Attention(nn.Module):
         if ctx.is_prefill and ctx.num_decode_seqs:
             return self._mixed(q, ctx)
         if ctx.is_prefill:
-            if self.k_cache is not None and ctx.block_tables is not None:
+            paged = self.k_cache is not None and ctx.block_tables is not None
+            if paged and self.k_cache.dtype == torch.float8_e4m3fn and not ctx.has_prefix \
+                    and k is not None:
+                paged = False       # nothing cached yet: attend to the exact K/V just projected
+            if paged:
                 o = ops.paged_attention_prefill(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q,
                                                 ctx.cu_seqlens_k, ctx.block_tables, self.scale,
-                                                ctx.max_seqlen_q)
+                                                ctx.max_seqlen_q, max_seqlen_k=ctx.max_seqlen_k,
+                                                total_k=ctx.total_k_tokens)
             else:
                 o = ops.flash_attention_prefill(q, k, v, ctx.cu_seqlens_q, self.scale,
                                                 ctx.max_seqlen_q)
@@ -108,7 +113,8 @@ class Attention(nn.Module):
             ops.paged_attention_prefill(q[:Tp], self.k_cache, self.v_cache,
                                         ctx.cu_seqlens_q[:Bp + 1], ctx.cu_seqlens_k[:Bp + 1],
                                         ctx.block_tables[:Bp], self.scale, ctx.max_seqlen_q,
-                                        out=o[:Tp])
+                                        out=o[:Tp], max_seqlen_k=ctx.max_seqlen_k,
+                                        total_k=ctx.total_k_tokens)
         ops.paged_attention_decode(q[Tp:Tp + Bd], self.k_cache, self.v_cache,
                                    ctx.block_tables[Bp:], ctx.context_lens, self.scale,
                                    ctx.max_context_len, out=o[Tp:Tp + Bd])

@@ -60,11 +60,14 @@ def _into(out, res):
 
 
 def paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k, block_tables, scale,
-                            max_seqlen_q=None, out=None):
-    """``out``: optional [T, Hq, D] destination (a view into a larger buffer is fine)."""
+                            max_seqlen_q=None, out=None, max_seqlen_k=None, total_k=None):
+    """``out``: optional [T, Hq, D] destination (a view into a larger buffer is fine).
+    ``max_seqlen_k`` / ``total_k`` (longest context, sum of contexts) spare an fp8 cache's
+    widening pass a device synchronisation and an oversized scratch buffer."""
     if _on_gpu(q):
         return _hip().paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k,
-                                              block_tables, scale, max_seqlen_q, out=out)
+                                              block_tables, scale, max_seqlen_q, out=out,
+                                              max_seqlen_k=max_seqlen_k, total_k=total_k)
     return _into(out, torch_ref.paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q,
                                                         cu_seqlens_k, block_tables, scale))
 

@@ -41,14 +41,18 @@ _silu = _sig("mvl_silu_and_mul", _c_void, _c_void, _c_long, _c_int, _c_long, _c_
              _c_void)
 _rope = _sig("mvl_qk_norm_rope_store", _c_void, _c_long, _c_void, _c_void, _c_void, _c_void,
              _c_float, _c_long, _c_int, _c_int, _c_int, _c_void, _c_void, _c_long, _c_long,
-             _c_long, _c_int, _c_void, _c_int, _c_void)
+             _c_long, _c_int, _c_void, _c_int, _c_int, _c_void)
+_gather_widen = _sig("mvl_kv_gather_widen", _c_void, _c_void, _c_long, _c_long, _c_long, _c_int,
+                     _c_void, _c_int, _c_void, _c_void, _c_void, _c_int, _c_int, _c_int, _c_int,
+                     _c_int, _c_void)
 _store = _sig("mvl_store_kvcache", _c_void, _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
               _c_long, _c_long, _c_int, _c_void, _c_long, _c_int, _c_int, _c_void)
 _sample = _sig("mvl_sample", _c_void, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void, _c_u64,
                _c_void, _c_void, _c_void, _c_int, _c_int, _c_void, _c_void, _c_void)
 _decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
                _c_long, _c_long, _c_void, _c_int, _c_void, _c_void, _c_long, _c_long, _c_void,
-               _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void)
+               _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+               _c_void)
 _prefill = _sig("mvl_flash_attention_prefill", _c_void, _c_long, _c_long, _c_void, _c_void,
                 _c_long, _c_long, _c_long, _c_void, _c_long, _c_long, _c_void, _c_void, _c_void,
                 _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -133,6 +137,13 @@ def silu_and_mul(x: torch.Tensor) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------- rope / store
+FP8_KV_DTYPE = torch.float8_e4m3fn        # gfx950 converts to / from the OCP e4m3 format
+
+
+def _kv_fp8(cache: Optional[torch.Tensor]) -> int:
+    return int(cache is not None and cache.dtype == FP8_KV_DTYPE)
+
+
 def _cache_strides(cache: torch.Tensor):
     """cache is logically [block, token, kv_head, d] with arbitrary physical order."""
     if cache.stride(3) != 1:
@@ -170,7 +181,8 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
                  eps, T, num_heads, num_kv_heads, head_dim,
                  k_cache.data_ptr() if have_cache else None,
                  v_cache.data_ptr() if have_cache else None, sb, st, sh, bs,
-                 slot_mapping.data_ptr() if have_cache else None, _dt(qkv), _stream()),
+                 slot_mapping.data_ptr() if have_cache else None, _dt(qkv),
+                 _kv_fp8(k_cache) if have_cache else 0, _stream()),
            "qk_norm_rope_store")
     q = qkv[:, :qs].view(T, num_heads, head_dim)
     k = qkv[:, qs:qs + ks].view(T, num_kv_heads, head_dim)
@@ -241,12 +253,17 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
                             cu_seqlens_q: torch.Tensor, cu_seqlens_k: torch.Tensor,
                             block_tables: torch.Tensor, scale: float,
                             max_seqlen_q: Optional[int] = None,
-                            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                            out: Optional[torch.Tensor] = None,
+                            max_seqlen_k: Optional[int] = None,
+                            total_k: Optional[int] = None) -> torch.Tensor:
     T, hq, d = q.shape
     hkv = k_cache.shape[2]
     cq, ck, bt = _i32(cu_seqlens_q), _i32(cu_seqlens_k), _i32(block_tables)
     if max_seqlen_q is None:
         max_seqlen_q = int((cq[1:] - cq[:-1]).max().item())
+    if _kv_fp8(k_cache):
+        return _prefill_over_fp8_cache(q, k_cache, v_cache, cq, ck, bt, scale, max_seqlen_q,
+                                       max_seqlen_k, total_k, out)
     qs_t, qs_h = _q_strides(q)
     sb, st, sh = _cache_strides(k_cache)
     assert _cache_strides(v_cache) == (sb, st, sh)
@@ -258,6 +275,34 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
                     out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
                     bt.data_ptr(), bt.stride(0), k_cache.shape[1], scale, cq.numel() - 1, hq, hkv,
                     d, max_seqlen_q, 1, _dt(q), _stream()), "paged_attention_prefill")
+    return out
+
+
+def _prefill_over_fp8_cache(q, k_cache, v_cache, cq, ck, bt, scale, max_seqlen_q, max_seqlen_k,
+                            total_k, out):
+    """fp8 cache: widen the contexts of the step's sequences into packed 16-bit K/V
+    (``kv_gather_widen``), then run the packed flash kernel with separate q / k lengths."""
+    T, hq, d = q.shape
+    hkv = k_cache.shape[2]
+    B = cq.numel() - 1
+    if max_seqlen_k is None:                                        # stand-alone call: ask the device
+        max_seqlen_k = int((ck[1:] - ck[:-1]).max().item())
+        total_k = int(ck[-1].item())
+    rows = total_k if total_k else B * max_seqlen_k                 # upper bound without a sync
+    k = torch.empty((rows, hkv, d), dtype=q.dtype, device=q.device)
+    v = torch.empty_like(k)
+    sb, st, sh = _cache_strides(k_cache)
+    assert _cache_strides(v_cache) == (sb, st, sh) and bt.stride(1) == 1
+    _check(_gather_widen(k_cache.data_ptr(), v_cache.data_ptr(), sb, st, sh, k_cache.shape[1],
+                         bt.data_ptr(), bt.stride(0), ck.data_ptr(), k.data_ptr(), v.data_ptr(), B,
+                         hkv, d, max_seqlen_k, _dt(q), _stream()), "kv_gather_widen")
+    qs_t, qs_h = _q_strides(q)
+    if out is None:
+        out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    _check(_prefill(q.data_ptr(), qs_t, qs_h, k.data_ptr(), v.data_ptr(), k.stride(0), k.stride(1),
+                    0, out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
+                    None, 0, 1, scale, B, hq, hkv, d, max_seqlen_q, 0, _dt(q), _stream()),
+           "flash_attention_prefill (fp8 cache)")
     return out
 
 
@@ -296,7 +341,7 @@ def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torc
     _check(_decode(q.data_ptr(), qs_b, qs_h, k_cache.data_ptr(), v_cache.data_ptr(), sb, st, sh,
                    bt.data_ptr(), bt.stride(0), ctx.data_ptr(), out.data_ptr(), out.stride(0),
                    out.stride(1), pa, pm, scale, B, hq, hkv, d, k_cache.shape[1], ns, _dt(q),
-                   _stream()), "paged_attention_decode")
+                   _kv_fp8(k_cache), _stream()), "paged_attention_decode")
     return out
 
 

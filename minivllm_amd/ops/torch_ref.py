@@ -95,6 +95,10 @@ def store_kvcache(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor,
         slots, key, value = slots[keep], key[keep], value[keep]
     blk = torch.div(slots, bs, rounding_mode="floor")
     off = slots - blk * bs
+    if k_cache.dtype == torch.float8_e4m3fn:      # indexed writes go through the byte view
+        k_cache.view(torch.uint8)[blk, off] = key.to(k_cache.dtype).view(torch.uint8)
+        v_cache.view(torch.uint8)[blk, off] = value.to(v_cache.dtype).view(torch.uint8)
+        return
     k_cache[blk, off] = key.to(k_cache.dtype)
     v_cache[blk, off] = value.to(v_cache.dtype)
 
@@ -165,7 +169,11 @@ def _gather_paged(cache: torch.Tensor, block_table: torch.Tensor, length: int) -
     bs = cache.shape[1]
     nb = (length + bs - 1) // bs
     blocks = block_table[:nb].long()
-    return cache[blocks].reshape(nb * bs, cache.shape[2], cache.shape[3])[:length]
+    if cache.dtype == torch.float8_e4m3fn:
+        got = cache.view(torch.uint8)[blocks].view(torch.float8_e4m3fn).float()
+    else:
+        got = cache[blocks]
+    return got.reshape(nb * bs, cache.shape[2], cache.shape[3])[:length]
 
 
 def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,

@@ -33,6 +33,7 @@ class Context:
     # tokens, the next num_decode_seqs rows are decode tokens whose lengths are context_lens
     num_decode_seqs: int = 0
     num_prefill_tokens: int = 0
+    total_k_tokens: int = 0                       # prefill: sum of context lengths (0 = unknown)
 
 
 _CONTEXT = Context()

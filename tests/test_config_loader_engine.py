@@ -260,3 +260,26 @@ def test_top_k_and_top_p_restrict_the_draw():
         SamplingParams(top_p=0.0)
     with pytest.raises(ValueError):
         SamplingParams(top_k=-1)
+
+
+def test_fp8_kv_cache_on_the_cpu_path():
+    """kv_cache_dtype="fp8": the cache tensor holds e4m3 bytes, prefix reuse and chunked prefill
+    read them back through the block table, and greedy outputs stay (nearly) those of the 32-bit
+    cache on this small model."""
+    rng = np.random.default_rng(41)
+    shared = rng.integers(0, 400, size=24).tolist()
+    prompts = [shared + rng.integers(0, 400, size=n).tolist() for n in (5, 30, 11)] + \
+              [rng.integers(0, 400, size=70).tolist()]
+    sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
+    ref_eng = _engine(max_num_batched_tokens=48)
+    want = ref_eng.generate(prompts, sp)["token_ids"]
+    ref_eng.exit()
+    eng = _engine(max_num_batched_tokens=48, kv_cache_dtype="fp8")
+    assert eng.model_runner.kv_cache.dtype == torch.float8_e4m3fn
+    got = eng.generate(prompts, sp)["token_ids"]
+    assert eng.scheduler.block_manager.num_prefix_hits > 0
+    eng.exit()
+    same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
+    assert same / 40 >= 0.7, (want, got)
+    with pytest.raises(ValueError):
+        EngineConfig.from_dict({"kv_cache_dtype": "int4", "device": "cpu"})

@@ -372,3 +372,35 @@ def test_top_k_top_p_on_gpu_with_graphs_and_sharded_logits(gpu):
                          gpu_memory_utilization=0.3))
     assert two.generate(prompts, sps)["token_ids"] == two.generate(prompts, greedy)["token_ids"]
     two.exit()
+
+
+def test_fp8_kv_cache_engine_on_gpu(gpu):
+    """fp8 KV cache end to end on the HIP path: the store kernel writes e4m3, decode graphs read
+    it directly, prefill over cached prefixes goes through the widening pass (also inside mixed
+    steps); twice the blocks fit the same memory and outputs stay close to the bf16 cache's."""
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    rng = np.random.default_rng(5)
+    shared = rng.integers(0, 2048, size=48).tolist()
+    prompts = [shared + rng.integers(0, 2048, size=int(n)).tolist() for n in (20, 150, 7, 90)] + \
+        _prompts(4, seed=23)
+    sp = SamplingParams(temperature=0, max_tokens=16, ignore_eos=True)
+    base = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8], max_cached_blocks=None,
+                          gpu_memory_utilization=0.05))
+    want = base.generate(prompts, sp)["token_ids"]
+    blocks16 = base.model_runner.num_kv_blocks
+    base.exit()
+    e = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8], max_cached_blocks=None,
+                       gpu_memory_utilization=0.05, kv_cache_dtype="fp8",
+                       enable_mixed_batches=True, max_num_batched_tokens=256))
+    assert e.model_runner.kv_cache.dtype == torch.float8_e4m3fn
+    assert e.model_runner.num_kv_blocks > 1.8 * blocks16
+    got = e.generate(prompts, sp)["token_ids"]
+    assert e.scheduler.block_manager.num_prefix_hits > 0 and e.scheduler.num_mixed_steps > 0
+    bm = e.scheduler.block_manager
+    assert bm.num_free_blocks == bm.num_blocks
+    e.exit()
+    assert [len(t) for t in got] == [len(t) for t in want]
+    first = sum(int(g[0] == w[0]) for g, w in zip(got, want))
+    same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
+    total = sum(len(x) for x in want)
+    assert first >= 6 and same / total > 0.5, (first, same, total)

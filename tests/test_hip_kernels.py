@@ -387,3 +387,74 @@ def test_skinny_gemm_swiglu(hip, dtype, M):
     close(hip.skinny_linear(x, w, swiglu=True), want, dtype, 4)
     assert hip.skinny_gemm_ok(x, w, swiglu=True)
     assert not hip.skinny_gemm_ok(torch.empty(17, K, device=DEV, dtype=dtype), w)
+
+
+# ------------------------------------------------------------------ fp8 KV cache
+FP8 = torch.float8_e4m3fn
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv,d,bs", [(32, 8, 128, 256), (16, 8, 64, 16), (8, 1, 128, 16)])
+def test_paged_decode_fp8_cache(hip, dtype, hq, hkv, d, bs):
+    """The decode kernel over an fp8 (e4m3) cache against the oracle over the same cache widened
+    to 16 bits: only the arithmetic may differ, the quantisation is shared."""
+    torch.manual_seed(21)
+    lens = [1, 31, 32, 33, 260, 1000, 77]
+    k = torch.randn(sum(lens), hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(sum(lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(k, v, lens, bs, hkv, d, dtype)
+    kc8, vc8 = kc.to(FP8), vc.to(FP8)
+    assert kc8.stride() == kc.stride()
+    q = torch.randn(len(lens), hq, d, device=DEV, dtype=dtype)
+    ctx = torch.tensor(lens, device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    want = ref.paged_attention_decode(q, kc8.to(dtype), vc8.to(dtype), tables, ctx, scale)
+    for ns in (1, 4):
+        got = hip.paged_attention_decode(q, kc8, vc8, tables, ctx, scale, num_splits=ns)
+        close(got, want, dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("d", [64, 128])
+def test_qk_norm_rope_store_into_fp8_cache(hip, dtype, d):
+    torch.manual_seed(22)
+    T, hq, hkv, bs, nb = 41, 8, 2, 16, 8
+    qkv = torch.randn(T, (hq + 2 * hkv) * d, device=DEV, dtype=dtype)
+    pos = torch.randint(0, 500, (T,), device=DEV, dtype=torch.int32)
+    cs = ref.build_cos_sin_cache(d, 512, 10000.0, DEV)
+    qw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype)
+    kw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype)
+    slots = torch.randperm(nb * bs, device=DEV)[:T].to(torch.int32)
+    slots[7] = -1
+    kc_r, vc_r = _logical_cache(nb, bs, hkv, d, dtype), _logical_cache(nb, bs, hkv, d, dtype)
+    kc_h, vc_h = _logical_cache(nb, bs, hkv, d, FP8), _logical_cache(nb, bs, hkv, d, FP8)
+    ref.qk_norm_rope_store(qkv.clone(), pos, cs, qw, kw, 1e-6, hq, hkv, d, kc_r, vc_r, slots)
+    q_h, k_h, v_h = hip.qk_norm_rope_store(qkv.clone(), pos, cs, qw, kw, 1e-6, hq, hkv, d, kc_h, vc_h, slots)
+    # fp8 has 3 mantissa bits: a 16-bit value that differs by one ulp between the two
+    # implementations may land in the neighbouring fp8 value
+    for got, want in ((kc_h, kc_r), (vc_h, vc_r)):
+        g, w = got.float(), want.to(FP8).float()
+        assert (g - w).abs().max() <= 0.13 * w.abs().max().clamp(min=1.0)
+        assert (g != w).float().mean() < 0.02
+    assert torch.equal(vc_h.float(), vc_r.to(FP8).float())      # v is copied, never recomputed
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("bs,hq,hkv,d", [(16, 16, 8, 128), (256, 32, 8, 128), (16, 8, 2, 64)])
+def test_paged_prefill_over_fp8_cache(hip, dtype, bs, hq, hkv, d):
+    torch.manual_seed(23)
+    k_lens = [300, 64, 513, 40, 256]
+    q_lens = [300, 1, 257, 40, 130]
+    k = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(k, v, k_lens, bs, hkv, d, dtype)
+    kc8, vc8 = kc.to(FP8), vc.to(FP8)
+    q = torch.randn(sum(q_lens), hq, d, device=DEV, dtype=dtype)
+    cq = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    ck = torch.tensor([0] + list(torch.tensor(k_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    want = ref.paged_attention_prefill(q, kc8.to(dtype), vc8.to(dtype), cq, ck, tables, scale)
+    close(hip.paged_attention_prefill(q, kc8, vc8, cq, ck, tables, scale), want, dtype)
+    got = hip.paged_attention_prefill(q, kc8, vc8, cq, ck, tables, scale, max_seqlen_q=300,
+                                      max_seqlen_k=513)            # the engine's call: no sync
+    close(got, want, dtype)

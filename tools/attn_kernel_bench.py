@@ -40,14 +40,17 @@ def main():
     ap.add_argument("--hkv", type=int, default=8)
     ap.add_argument("--prefill", default="16x1024,4x4096,1x16384,1x32768")
     ap.add_argument("--decode", default="256x1024,64x4096,8x16384,1x32768")
+    ap.add_argument("--kv-fp8", action="store_true", help="fp8 (e4m3) KV cache")
     a = ap.parse_args()
+    eb = 1 if a.kv_fp8 else 2
+    q8 = (lambda c: c.to(torch.float8_e4m3fn)) if a.kv_fp8 else (lambda c: c)
     hq, hkv, d, bs = a.hq, a.hkv, 128, 256
     scale = 1 / math.sqrt(d)
     if a.mode in ("prefill", "both"):
         for spec in a.prefill.split(","):
             B, S = map(int, spec.split("x"))
             nblk = (S + bs - 1) // bs
-            kc, vc = cache(B * nblk, bs, hkv, d), cache(B * nblk, bs, hkv, d)
+            kc, vc = q8(cache(B * nblk, bs, hkv, d)), q8(cache(B * nblk, bs, hkv, d))
             q = torch.randn(B * S, hq, d, device="cuda", dtype=torch.bfloat16)
             cu = torch.arange(0, (B + 1) * S, S, device="cuda", dtype=torch.int32)
             bt = torch.arange(B * nblk, device="cuda", dtype=torch.int32).view(B, nblk)
@@ -59,12 +62,12 @@ def main():
         for spec in a.decode.split(","):
             B, S = map(int, spec.split("x"))
             nblk = (S + bs - 1) // bs
-            kc, vc = cache(B * nblk, bs, hkv, d), cache(B * nblk, bs, hkv, d)
+            kc, vc = q8(cache(B * nblk, bs, hkv, d)), q8(cache(B * nblk, bs, hkv, d))
             q = torch.randn(B, hq, d, device="cuda", dtype=torch.bfloat16)
             ctx = torch.full((B,), S, device="cuda", dtype=torch.int32)
             bt = torch.arange(B * nblk, device="cuda", dtype=torch.int32).view(B, nblk)
             t = timeit(lambda: hip.paged_attention_decode(q, kc, vc, bt, ctx, scale, S), a.iters)
-            by = 2 * B * S * hkv * d * 2
+            by = 2 * B * S * hkv * d * eb
             print(f"decode  B={B} ctx={S}: {t*1e3:8.3f} ms  {by/t/1e12:6.2f} TB/s KV stream", flush=True)
             del kc, vc, q
 
