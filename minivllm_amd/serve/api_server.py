@@ -267,6 +267,7 @@ def main(argv: Optional[List[str]] = None) -> None:
     ap.add_argument("--min-prefill-tokens", type=int, default=0)
     ap.add_argument("--max-prefill-delay-ms", type=float, default=0.0)
     ap.add_argument("--mixed-batches", action="store_true")
+    ap.add_argument("--kv-cache-dtype", choices=["auto", "fp8"], default="auto")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--enforce-eager", action="store_true")
     a = ap.parse_args(argv)
@@ -275,7 +276,7 @@ def main(argv: Optional[List[str]] = None) -> None:
            "max_num_batched_tokens": a.max_num_batched_tokens,
            "max_model_length": a.max_model_length, "min_prefill_tokens": a.min_prefill_tokens,
            "max_prefill_delay_ms": a.max_prefill_delay_ms,
-           "enable_mixed_batches": a.mixed_batches,
+           "enable_mixed_batches": a.mixed_batches, "kv_cache_dtype": a.kv_cache_dtype,
            "device": a.device, "enforce_eager": a.enforce_eager or a.device != "cuda",
            "log_stats": False}
     if a.checkpoint_path:
