@@ -146,6 +146,10 @@ def test_tp2_gloo_matches_tp1():
     # mixed prefill + decode steps cross the control channel like any other batch
     mixed, stats = _generate(2, port + 2, enable_mixed_batches=True, max_num_batched_tokens=40)
     assert mixed == single and stats[2] > 0
+    # fp8 KV cache: quantisation is per element, so sharding the KV heads changes nothing
+    q1, _ = _generate(1, port + 3, kv_cache_dtype="fp8")
+    q2, _ = _generate(2, port + 4, kv_cache_dtype="fp8")
+    assert q2 == q1
 
 
 def test_tp4_gloo_matches_tp1():
