@@ -36,16 +36,29 @@ namespace {
 constexpr int kTile = 32;          // tokens per wave iteration
 constexpr int kWaves = 4;
 
-// 16 fp8 (e4m3) values -> 16 values of the 16-bit type CODE, as two 16-byte chunks
+// 16 fp8 (e4m3) values -> 16 values of the 16-bit type CODE, as two 16-byte chunks.  The
+// scaled conversion with scale 1 is exact (every e4m3 value is a bf16 and an fp16 value) and
+// one instruction per pair, half of fp8 -> fp32 -> 16 bits.
+template <int CODE>
+__device__ __forceinline__ uint32_t widen_fp8x2(uint32_t v, bool high_word) {
+    if constexpr (CODE == 0) {
+        return high_word
+            ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, true))
+            : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, false));
+    } else {
+        return high_word
+            ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v, 1.0f, true))
+            : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v, 1.0f, false));
+    }
+}
+
 template <int CODE>
 __device__ __forceinline__ void widen_fp8x16(u32x4_t v, u32x4_t& lo, u32x4_t& hi) {
     uint32_t o[8];
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
-        const auto f01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], false);
-        const auto f23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], true);
-        o[2 * w] = pack2<CODE>(f01[0], f01[1]);
-        o[2 * w + 1] = pack2<CODE>(f23[0], f23[1]);
+        o[2 * w] = widen_fp8x2<CODE>(v[w], false);
+        o[2 * w + 1] = widen_fp8x2<CODE>(v[w], true);
     }
     lo = u32x4_t{o[0], o[1], o[2], o[3]};
     hi = u32x4_t{o[4], o[5], o[6], o[7]};
@@ -114,9 +127,22 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     int st_row[ITER], st_ch[ITER];
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-        const int c = i * 64 + lane;
-        st_row[i] = c / GCPR;
-        st_ch[i] = c % GCPR;
+        if constexpr (!KV8) {
+            const int c = i * 64 + lane;
+            st_row[i] = c / GCPR;
+            st_ch[i] = c % GCPR;
+        } else if constexpr (D == 128) {
+            // An fp8 chunk widens into LDS chunks 2 ch and 2 ch + 1, so 8 lanes on one row would
+            // store to even chunks only: half the 32 banks, twice (ds_write_b128 is banked per
+            // 8 consecutive lanes).  Rows r and r + 4 differ in the low bit of their swizzle,
+            // so 4 chunks of each per lane group cover all banks.  One load instruction still
+            // reads 8 whole rows (1 KB contiguous).
+            st_ch[i] = ((lane >> 3) & 1) * 4 + (lane & 3);
+            st_row[i] = i * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 4) & 3);
+        } else {
+            st_ch[i] = lane & 3;
+            st_row[i] = i * 16 + ((lane >> 2) & 1) * 4 + ((lane >> 3) & 3) + ((lane >> 5) & 1) * 8;
+        }
     }
 
     auto load_block_ids = [&](int tile, int (&ids)[ITER]) {
@@ -220,13 +246,18 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         // ---- O^T[d][head] += V^T . P^T
         const int tr_row = 4 * q4 + (c16 >> 2);
         const int tr_sub = (c16 & 1) * 8;
+        // the running maximum settles after the first tiles of a context: skip the rescale of
+        // the 32 accumulators (a round trip through the VALU) whenever no lane's maximum moved
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+            for (int n = 0; n < NDB; ++n) acc_o[n] *= alpha;
+        }
 #pragma unroll
         for (int n = 0; n < NDB; ++n) {
             const int ch = 2 * n + ((c16 & 3) >> 1);
             const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(tr_row, ch) + tr_sub);
             const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(16 + tr_row, ch) + tr_sub);
             const s16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            acc_o[n] *= alpha;
             acc_o[n] = DT::mfma16(__builtin_bit_cast(vec8, a), pfrag, acc_o[n]);
         }
     }
