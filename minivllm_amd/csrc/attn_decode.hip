@@ -121,7 +121,12 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     }
 
     const int* bt = block_tables + (long)b * bt_stride;
-    const long head_off = (long)kvh * cs_h;
+    // Address arithmetic in 32 bits wherever the launcher's range checks allow: only the block
+    // base is a 64-bit product (with the fp8 cache the waves issue instructions nearly half of
+    // their cycles, and the addresses of a tile were a quarter of them).
+    const unsigned cs_b_bytes = (unsigned)(cs_b * EB);
+    const unsigned cs_t_bytes = (unsigned)(cs_t * EB);
+    const unsigned head_off_bytes = (unsigned)((long)kvh * cs_h * EB);
 
     // per-lane staging coordinates: chunk id = i*64 + lane -> (row, ch)
     int st_row[ITER], st_ch[ITER];
@@ -144,20 +149,23 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
             st_row[i] = i * 16 + ((lane >> 2) & 1) * 4 + ((lane >> 3) & 3) + ((lane >> 5) & 1) * 8;
         }
     }
+    unsigned st_const[ITER];                   // byte offset of the lane's chunk inside a block
+#pragma unroll
+    for (int i = 0; i < ITER; ++i) st_const[i] = head_off_bytes + st_ch[i] * 16;
 
     auto load_block_ids = [&](int tile, int (&ids)[ITER]) {
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
-            const int tok = min(tile * kTile + st_row[i], L - 1);
+            const unsigned tok = (unsigned)min(tile * kTile + st_row[i], L - 1);
             ids[i] = bt[tok >> bs_log2];
         }
     };
     auto issue_loads = [&](int tile, const int (&ids)[ITER], u32x4_t (&kr)[ITER], u32x4_t (&vr)[ITER]) {
 #pragma unroll
         for (int i = 0; i < ITER; ++i) {
-            const int tok = min(tile * kTile + st_row[i], L - 1);
-            const long off = ((long)ids[i] * cs_b + (long)(tok & bs_mask) * cs_t + head_off) * EB
-                             + st_ch[i] * 16;                      // bytes
+            const unsigned tok = (unsigned)min(tile * kTile + st_row[i], L - 1);
+            const unsigned in_block = __umul24(tok & (unsigned)bs_mask, cs_t_bytes) + st_const[i];
+            const unsigned long off = (unsigned long)(unsigned)ids[i] * cs_b_bytes + in_block;   // bytes
             // every KV byte is used once per step: keep it from displacing weights in L2 / MALL
             kr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(k_cache + off));
             vr[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(v_cache + off));
@@ -343,6 +351,11 @@ int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void*
                   int Hkv, int block_size, int nsplit, hipStream_t st) {
     int bs_log2 = 0;
     while ((1 << bs_log2) < block_size) ++bs_log2;
+    // the kernel forms in-block byte offsets in 32 bits (token stride through a 24-bit multiply)
+    constexpr long EB = KV8 ? 1 : 2;
+    if (csb <= 0 || cst <= 0 || csh < 0 || csb * EB >= (1L << 32) || cst * EB >= (1L << 24) ||
+        ((long)block_size * cst + (long)Hkv * csh) * EB + D * EB >= (1L << 31))
+        return -1;
     const int G = Hq / Hkv;
     const int ngrp = (G + 15) / 16;
     dim3 grid(nsplit, Hkv * ngrp, B);
