@@ -36,6 +36,23 @@ namespace {
 constexpr int kTile = 32;          // tokens per wave iteration
 constexpr int kWaves = 4;
 
+// Byte offset of 16-byte chunk `ch` of row `row` in a wave's [32 rows][CPR chunks] tile image.
+// The XOR pattern is chosen for the lane groups in which the LDS services this kernel's
+// accesses (all free of bank conflicts for 256-byte rows):
+//   * ds_read_b128 of K fragments (lane = row c16, chunk 4 s + q4) is serviced in the groups
+//     {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...: rows 0-3 and 12-15 of one chunk column
+//     meet rows 4-11 of the next one, so row -> x(row) ^ [4 <= row <= 11] must be a bijection
+//     of 16 rows onto the 16 chunk positions;
+//   * ds_read_b64_tr_b16 of V fragments is serviced per 32 lanes = 8 rows x 2 chunks x 2 halves:
+//     x >> 1 must take 8 values over 8 consecutive rows;
+//   * staging stores of an fp8 tile pair rows r and r + 4 in a group of 8 lanes: their x must
+//     differ in bit 0.
+template <int CPR>
+__device__ __forceinline__ int dec_tile_off(int row, int ch) {
+    const int x = (((row & 7) << 1) | ((row >> 2) & 1)) & (CPR - 1);
+    return row * (CPR * 16) + ((ch ^ x) << 4);
+}
+
 // 16 fp8 (e4m3) values -> 16 values of the 16-bit type CODE, as two 16-byte chunks.  The
 // scaled conversion with scale 1 is exact (every e4m3 value is a bf16 and an fp16 value) and
 // one instruction per pair, half of fp8 -> fp32 -> 16 bits.
@@ -139,8 +156,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         } else if constexpr (D == 128) {
             // An fp8 chunk widens into LDS chunks 2 ch and 2 ch + 1, so 8 lanes on one row would
             // store to even chunks only: half the 32 banks, twice (ds_write_b128 is banked per
-            // 8 consecutive lanes).  Rows r and r + 4 differ in the low bit of their swizzle,
-            // so 4 chunks of each per lane group cover all banks.  One load instruction still
+            // 8 consecutive lanes).  Rows r and r + 4 differ in the low bit of their XOR
+            // pattern, so 4 chunks of each per lane group cover all banks.  One load instruction still
             // reads 8 whole rows (1 KB contiguous).
             st_ch[i] = ((lane >> 3) & 1) * 4 + (lane & 3);
             st_row[i] = i * 8 + ((lane >> 2) & 1) * 4 + ((lane >> 4) & 3);
@@ -193,8 +210,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         for (int i = 0; i < ITER; ++i) {
             if constexpr (KV8) {
                 u32x4_t lo, hi;
-                const int o0 = tile_off<CPR>(st_row[i], 2 * st_ch[i]);
-                const int o1 = tile_off<CPR>(st_row[i], 2 * st_ch[i] + 1);
+                const int o0 = dec_tile_off<CPR>(st_row[i], 2 * st_ch[i]);
+                const int o1 = dec_tile_off<CPR>(st_row[i], 2 * st_ch[i] + 1);
                 widen_fp8x16<CODE>(kreg[i], lo, hi);
                 *reinterpret_cast<u32x4_t*>(k_lds + o0) = lo;
                 *reinterpret_cast<u32x4_t*>(k_lds + o1) = hi;
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
                 *reinterpret_cast<u32x4_t*>(v_lds + o0) = lo;
                 *reinterpret_cast<u32x4_t*>(v_lds + o1) = hi;
             } else {
-                const int o = tile_off<CPR>(st_row[i], st_ch[i]);
+                const int o = dec_tile_off<CPR>(st_row[i], st_ch[i]);
                 *reinterpret_cast<u32x4_t*>(k_lds + o) = kreg[i];
                 *reinterpret_cast<u32x4_t*>(v_lds + o) = vreg[i];
             }
@@ -220,7 +237,7 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
                 const u32x4_t kv = *reinterpret_cast<const u32x4_t*>(
-                    k_lds + tile_off<CPR>(16 * sub + c16, 4 * s + q4));
+                    k_lds + dec_tile_off<CPR>(16 * sub + c16, 4 * s + q4));
                 s_acc[sub] = DT::mfma16(__builtin_bit_cast(vec8, kv), qfrag[s], s_acc[sub]);
             }
         }
@@ -263,8 +280,8 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 #pragma unroll
         for (int n = 0; n < NDB; ++n) {
             const int ch = 2 * n + ((c16 & 3) >> 1);
-            const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(tr_row, ch) + tr_sub);
-            const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(16 + tr_row, ch) + tr_sub);
+            const s16x4_t lo = lds_read_tr16(v_lds, dec_tile_off<CPR>(tr_row, ch) + tr_sub);
+            const s16x4_t hi = lds_read_tr16(v_lds, dec_tile_off<CPR>(16 + tr_row, ch) + tr_sub);
             const s16x8_t a = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             acc_o[n] = DT::mfma16(__builtin_bit_cast(vec8, a), pfrag, acc_o[n]);
         }
