@@ -193,6 +193,9 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
 def store_kvcache(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor,
                   v_cache: torch.Tensor, slot_mapping: torch.Tensor) -> None:
     T, hkv, d = key.shape
+    if _kv_fp8(k_cache):
+        raise NotImplementedError("the stand-alone scatter copies 16-bit values; an fp8 cache is "
+                                  "written by qk_norm_rope_store")
     assert key.stride(2) == 1 and key.stride(1) == d and value.stride(2) == 1 and value.stride(1) == d
     sb, st, sh = _cache_strides(k_cache)
     assert _cache_strides(v_cache) == (sb, st, sh)
