@@ -23,6 +23,15 @@ __global__ void rms_norm_kernel(const uint16_t* __restrict__ x, uint16_t* residu
     const int nchunk = hidden >> 3;
     const u32x4_t* xr = reinterpret_cast<const u32x4_t*>(x + row * x_stride);
     u32x4_t* rr = ADD ? reinterpret_cast<u32x4_t*>(residual + row * r_stride) : nullptr;
+    // the weights are fetched together with the row: their latency overlaps the row's and the
+    // reduction instead of following the barrier (the kernel is a chain of memory round trips)
+    const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(weight);
+    u32x4_t wv[MAXC];
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * blockDim.x;
+        wv[i] = c < nchunk ? wr[c] : u32x4_t{0, 0, 0, 0};
+    }
     float v[MAXC][8];
     float ss = 0.f;
 #pragma unroll
@@ -44,14 +53,13 @@ __global__ void rms_norm_kernel(const uint16_t* __restrict__ x, uint16_t* residu
     }
     ss = block_sum(ss, scratch);
     const float rstd = rsqrtf(ss / (float)hidden + eps);
-    const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(weight);
     u32x4_t* orow = reinterpret_cast<u32x4_t*>(out + row * o_stride);
 #pragma unroll
     for (int i = 0; i < MAXC; ++i) {
         const int c = threadIdx.x + i * blockDim.x;
         if (c < nchunk) {
             float w[8], o[8];
-            unpack8<CODE>(wr[c], w);
+            unpack8<CODE>(wv[i], w);
 #pragma unroll
             for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rstd * w[j];
             orow[c] = pack8<CODE>(o);
