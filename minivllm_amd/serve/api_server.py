@@ -7,7 +7,8 @@
 Endpoints: ``POST /v1/completions`` and ``POST /v1/chat/completions`` (JSON in, JSON or
 server-sent events out with ``"stream": true``), ``GET /v1/models``, ``GET /health``,
 ``GET /metrics`` (Prometheus text format).  A client that disconnects mid-stream aborts its
-request, which returns its KV blocks to the pool.  Prompts may be text or token-id lists (random
+request, which returns its KV blocks to the pool; so does a match of one of the request's
+``stop`` strings (the text ends before it, ``finish_reason`` is ``"stop"``).  Prompts may be text or token-id lists (random
 weights and the byte-level fallback tokenizer make token ids the practical choice offline).
 
 The reference has no server (its entry point is the offline demo, reference: main.py:43-71); the
@@ -46,6 +47,33 @@ class _TextStream:
         return delta
 
 
+class _StopMatcher:
+    """OpenAI ``stop`` strings over a text stream: text is released up to the earliest stop
+    string (which is not part of the output), and while none has matched, the longest tail
+    that could still grow into one is held back."""
+
+    def __init__(self, stops: List[str]):
+        self.stops, self.buf, self.hit = stops, "", False
+
+    def feed(self, piece: str, final: bool = False) -> str:
+        if self.hit:
+            return ""
+        self.buf += piece
+        cut = min((i for i in (self.buf.find(st) for st in self.stops) if i >= 0), default=-1)
+        if cut >= 0:
+            out, self.buf, self.hit = self.buf[:cut], "", True
+            return out
+        hold = 0
+        if not final:
+            for st in self.stops:
+                for n in range(min(len(st) - 1, len(self.buf)), hold, -1):
+                    if self.buf.endswith(st[:n]):
+                        hold = n
+                        break
+        out, self.buf = self.buf[:len(self.buf) - hold], self.buf[len(self.buf) - hold:]
+        return out
+
+
 def _metrics():
     from prometheus_client import CollectorRegistry, Counter, Gauge, Histogram
     reg = CollectorRegistry()
@@ -71,13 +99,28 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
     max_len = engine.cfg.max_model_length
 
     def _account(h: RequestHandle) -> None:
-        m["requests"].labels(h.finish_reason or "unknown").inc()
+        m["requests"].labels(_reason(h) or "unknown").inc()
         m["prompt_tokens"].inc(h.num_prompt_tokens)
         m["generated_tokens"].inc(len(h.token_ids))
         if h.first_token_at is not None:
             m["ttft"].observe(h.first_token_at - h.submitted_at)
         if h.finished_at is not None:
             m["e2e"].observe(h.finished_at - h.submitted_at)
+
+    def _reason(h: RequestHandle) -> Optional[str]:
+        return "stop" if getattr(h, "stop_text", None) is not None else h.finish_reason
+
+    def _text(h: RequestHandle) -> str:
+        cut = getattr(h, "stop_text", None)
+        return cut if cut is not None else engine.tokenizer.decode(h.token_ids,
+                                                                   skip_special_tokens=True)
+
+    def _stops(body: dict) -> List[str]:
+        st = body.get("stop")
+        st = [] if st is None else [st] if isinstance(st, str) else st
+        if not isinstance(st, list) or len(st) > 8 or not all(isinstance(x, str) and x for x in st):
+            raise HTTPException(400, "stop must be a non-empty string or a list of up to 8 of them")
+        return st
 
     def _params(body: dict) -> SamplingParams:
         max_tokens = body.get("max_tokens")
@@ -108,17 +151,26 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
         pt, ct = sum(h.num_prompt_tokens for h in hs), sum(len(h.token_ids) for h in hs)
         return {"prompt_tokens": pt, "completion_tokens": ct, "total_tokens": pt + ct}
 
-    async def _collect(h: RequestHandle) -> None:
+    async def _collect(h: RequestHandle, stops: List[str]) -> None:
+        ts, sm, text = _TextStream(engine.tokenizer), _StopMatcher(stops), []
         try:
-            async for _ in h:
-                pass
+            async for toks in h:
+                if stops and not sm.hit:
+                    text.append(sm.feed(ts.push(toks)))
+                    if sm.hit:                              # the rest of the generation is not wanted
+                        h.stop_text = "".join(text)
+                        h.cancel()
+            if stops and not sm.hit:
+                text.append(sm.feed(ts.push([], final=True), final=True))
+                if sm.hit:
+                    h.stop_text = "".join(text)
         finally:
             if not h.finished:
                 h.cancel()
 
-    async def _run_all(hs: List[RequestHandle]) -> None:
+    async def _run_all(hs: List[RequestHandle], stops: List[str] = ()) -> None:
         try:
-            await asyncio.gather(*(_collect(h) for h in hs))
+            await asyncio.gather(*(_collect(h, list(stops)) for h in hs))
         except ValueError as e:                             # rejected by the scheduler
             raise HTTPException(400, str(e))
         finally:
@@ -140,16 +192,32 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
     def _sse(obj) -> bytes:
         return f"data: {json.dumps(obj)}\n\n".encode()
 
-    async def _stream(hs: List[RequestHandle], make_chunk, request: Request):
+    async def _stream(hs: List[RequestHandle], make_chunk, request: Request,
+                      stops: List[str] = ()):
         """Interleave the token streams of ``hs`` as server-sent events."""
         out: asyncio.Queue = asyncio.Queue()
 
         async def pump(i: int, h: RequestHandle):
-            ts = _TextStream(engine.tokenizer)
+            ts, sm = _TextStream(engine.tokenizer), _StopMatcher(list(stops))
             try:
                 async for toks in h:
-                    await out.put(make_chunk(i, ts.push(toks), toks, None))
-                await out.put(make_chunk(i, ts.push([], final=True), [], h.finish_reason))
+                    if sm.hit:
+                        continue                            # draining after the cancel
+                    piece = ts.push(toks)
+                    if stops:
+                        piece = sm.feed(piece)
+                        if sm.hit:
+                            h.stop_text = ""                # marks the outcome for the metrics
+                            h.cancel()
+                    await out.put(make_chunk(i, piece, toks, None))
+                tail = ""
+                if not sm.hit:
+                    tail = ts.push([], final=True)
+                    if stops:
+                        tail = sm.feed(tail, final=True)
+                        if sm.hit:
+                            h.stop_text = ""
+                await out.put(make_chunk(i, tail, [], _reason(h)))
             except Exception as e:
                 await out.put({"error": {"message": str(e), "type": type(e).__name__}})
             await out.put(None)
@@ -194,7 +262,7 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
     @app.post("/v1/completions")
     async def completions(request: Request):
         body = await _body(request)
-        sp, prompts = _params(body), _prompts(body.get("prompt"))
+        sp, prompts, stops = _params(body), _prompts(body.get("prompt")), _stops(body)
         loop = asyncio.get_running_loop()
         rid, created = f"cmpl-{uuid.uuid4().hex}", int(time.time())
         hs = [engine.submit(p, sp, loop=loop) for p in prompts]
@@ -204,13 +272,13 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
                         "model": model_name,
                         "choices": [{"index": i, "text": text, "token_ids": toks,
                                      "finish_reason": reason}]}
-            return StreamingResponse(_stream(hs, chunk, request), media_type="text/event-stream")
-        await _run_all(hs)
-        tok = engine.tokenizer
+            return StreamingResponse(_stream(hs, chunk, request, stops),
+                                     media_type="text/event-stream")
+        await _run_all(hs, stops)
         return JSONResponse({
             "id": rid, "object": "text_completion", "created": created, "model": model_name,
-            "choices": [{"index": i, "text": tok.decode(h.token_ids, skip_special_tokens=True),
-                         "token_ids": h.token_ids, "finish_reason": h.finish_reason}
+            "choices": [{"index": i, "text": _text(h),
+                         "token_ids": h.token_ids, "finish_reason": _reason(h)}
                         for i, h in enumerate(hs)],
             "usage": _usage(hs)})
 
@@ -226,7 +294,7 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
         except Exception:                                   # tokenizer without a template
             text = "".join(f"<|im_start|>{x['role']}\n{x['content']}<|im_end|>\n" for x in msgs)
             text += "<|im_start|>assistant\n"
-        sp = _params(body)
+        sp, stops = _params(body), _stops(body)
         rid, created = f"chatcmpl-{uuid.uuid4().hex}", int(time.time())
         h = engine.submit(text, sp, loop=asyncio.get_running_loop())
         if body.get("stream"):
@@ -239,13 +307,13 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
                 return {"id": rid, "object": "chat.completion.chunk", "created": created,
                         "model": model_name,
                         "choices": [{"index": i, "delta": delta, "finish_reason": reason}]}
-            return StreamingResponse(_stream([h], chunk, request), media_type="text/event-stream")
-        await _run_all([h])
+            return StreamingResponse(_stream([h], chunk, request, stops),
+                                     media_type="text/event-stream")
+        await _run_all([h], stops)
         return JSONResponse({
             "id": rid, "object": "chat.completion", "created": created, "model": model_name,
-            "choices": [{"index": 0, "finish_reason": h.finish_reason,
-                         "message": {"role": "assistant",
-                                     "content": tok.decode(h.token_ids, skip_special_tokens=True)}}],
+            "choices": [{"index": 0, "finish_reason": _reason(h),
+                         "message": {"role": "assistant", "content": _text(h)}}],
             "usage": _usage([h])})
 
     return app

@@ -149,7 +149,30 @@ def test_http_api(server_engine, offline_tokens):
     assert client.post("/v1/completions", json={"prompt": "x", "max_tokens": 0}).status_code == 400
     assert client.post("/v1/completions",
                        json={"prompt": list(range(1, 95)), "max_tokens": 50}).status_code == 400
+    # stop strings: the text ends before the first one, the request is cut short
+    full = client.post("/v1/completions", json={"prompt": ps[0], "max_tokens": 10, "temperature": 0,
+                                                "ignore_eos": True}).json()["choices"][0]["text"]
+    assert len(full) >= 4
+    stop = full[2:4]
+    want = full[:full.find(stop)]
+    r = client.post("/v1/completions", json={"prompt": ps[0], "max_tokens": 10, "temperature": 0,
+                                             "ignore_eos": True, "stop": stop}).json()["choices"][0]
+    assert r["text"] == want and r["finish_reason"] == "stop" and len(r["token_ids"]) <= 10
+    pieces, reasons = [], []
+    with client.stream("POST", "/v1/completions",
+                       json={"prompt": ps[0], "max_tokens": 10, "temperature": 0, "ignore_eos": True,
+                             "stream": True, "stop": ["never-there", stop]}) as resp:
+        for line in resp.iter_lines():
+            if line.startswith("data: ") and line != "data: [DONE]":
+                ch = json.loads(line[6:])["choices"][0]
+                pieces.append(ch["text"])
+                reasons.append(ch["finish_reason"])
+    assert "".join(pieces) == want and reasons[-1] == "stop"
+    assert client.post("/v1/completions", json={"prompt": "x", "stop": [""]}).status_code == 400
+    st = server_engine.stats()
+    assert st["running"] == 0 and st["kv_blocks_free"] == st["kv_blocks"]
     text = client.get("/metrics").text
+    assert 'minivllm_requests_total{finish_reason="stop"}' in text
     assert 'minivllm_requests_total{finish_reason="length"}' in text
     assert "minivllm_generated_tokens_total" in text and "minivllm_kv_blocks_free" in text
 
