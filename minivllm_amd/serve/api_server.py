@@ -122,6 +122,17 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
             raise HTTPException(400, "stop must be a non-empty string or a list of up to 8 of them")
         return st
 
+    def _n(body: dict) -> int:
+        """``n`` completions per prompt: the copies share the prompt's KV blocks through the
+        prefix cache and differ by their sampling noise (keyed by the batch row)."""
+        try:
+            n = int(body.get("n") or 1)
+        except (TypeError, ValueError):
+            n = 0
+        if not 1 <= n <= 16:
+            raise HTTPException(400, "n must be an integer between 1 and 16")
+        return n
+
     def _params(body: dict) -> SamplingParams:
         max_tokens = body.get("max_tokens")
         if max_tokens is None:
@@ -265,7 +276,8 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
         sp, prompts, stops = _params(body), _prompts(body.get("prompt")), _stops(body)
         loop = asyncio.get_running_loop()
         rid, created = f"cmpl-{uuid.uuid4().hex}", int(time.time())
-        hs = [engine.submit(p, sp, loop=loop) for p in prompts]
+        n = _n(body)
+        hs = [engine.submit(p, sp, loop=loop) for p in prompts for _ in range(n)]
         if body.get("stream"):
             def chunk(i, text, toks, reason):
                 return {"id": rid, "object": "text_completion", "created": created,
@@ -294,27 +306,29 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
         except Exception:                                   # tokenizer without a template
             text = "".join(f"<|im_start|>{x['role']}\n{x['content']}<|im_end|>\n" for x in msgs)
             text += "<|im_start|>assistant\n"
-        sp, stops = _params(body), _stops(body)
+        sp, stops, n = _params(body), _stops(body), _n(body)
         rid, created = f"chatcmpl-{uuid.uuid4().hex}", int(time.time())
-        h = engine.submit(text, sp, loop=asyncio.get_running_loop())
+        loop = asyncio.get_running_loop()
+        hs = [engine.submit(text, sp, loop=loop) for _ in range(n)]
         if body.get("stream"):
-            first = [True]
+            first = [True] * n
 
             def chunk(i, piece, toks, reason):
                 delta = {"content": piece}
-                if first[0]:
-                    delta["role"], first[0] = "assistant", False
+                if first[i]:
+                    delta["role"], first[i] = "assistant", False
                 return {"id": rid, "object": "chat.completion.chunk", "created": created,
                         "model": model_name,
                         "choices": [{"index": i, "delta": delta, "finish_reason": reason}]}
-            return StreamingResponse(_stream([h], chunk, request, stops),
+            return StreamingResponse(_stream(hs, chunk, request, stops),
                                      media_type="text/event-stream")
-        await _run_all([h], stops)
+        await _run_all(hs, stops)
         return JSONResponse({
             "id": rid, "object": "chat.completion", "created": created, "model": model_name,
-            "choices": [{"index": 0, "finish_reason": _reason(h),
-                         "message": {"role": "assistant", "content": _text(h)}}],
-            "usage": _usage([h])})
+            "choices": [{"index": i, "finish_reason": _reason(h),
+                         "message": {"role": "assistant", "content": _text(h)}}
+                        for i, h in enumerate(hs)],
+            "usage": _usage(hs)})
 
     return app
 

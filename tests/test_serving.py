@@ -169,6 +169,16 @@ def test_http_api(server_engine, offline_tokens):
                 reasons.append(ch["finish_reason"])
     assert "".join(pieces) == want and reasons[-1] == "stop"
     assert client.post("/v1/completions", json={"prompt": "x", "stop": [""]}).status_code == 400
+    # n completions per prompt: same prompt, different sampling noise, shared prompt blocks
+    r = client.post("/v1/completions", json={"prompt": ps[1], "max_tokens": 8, "temperature": 1.0,
+                                             "ignore_eos": True, "n": 3}).json()
+    assert [c["index"] for c in r["choices"]] == [0, 1, 2]
+    assert r["usage"]["completion_tokens"] == 24 and r["usage"]["prompt_tokens"] == 3 * len(ps[1])
+    assert len({tuple(c["token_ids"]) for c in r["choices"]}) > 1
+    r = client.post("/v1/chat/completions", json={"messages": [{"role": "user", "content": "hi"}],
+                                                  "max_tokens": 3, "n": 2}).json()
+    assert len(r["choices"]) == 2
+    assert client.post("/v1/completions", json={"prompt": "x", "n": 99}).status_code == 400
     st = server_engine.stats()
     assert st["running"] == 0 and st["kv_blocks_free"] == st["kv_blocks"]
     text = client.get("/metrics").text
