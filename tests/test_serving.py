@@ -283,3 +283,18 @@ def test_concurrent_clients_with_random_cancellations(server_engine):
     assert any(r == "abort" for r, _ in results) and any(r == "length" for r, _ in results)
     st = server_engine.stats()
     assert st["running"] == 0 and st["waiting"] == 0 and st["kv_blocks_free"] == st["kv_blocks"]
+
+
+def test_stop_matcher_holds_back_partial_matches():
+    from minivllm_amd.serve.api_server import _StopMatcher
+    m = _StopMatcher(["END", "\n\n"])
+    out = [m.feed(x) for x in ["hello E", "N", "Dx", " more"]]
+    assert "".join(out) == "hello " and m.hit                  # cut before the stop string
+    m = _StopMatcher(["abc"])
+    assert [m.feed("xa"), m.feed("b")] == ["x", ""] and not m.hit      # "ab" may still become "abc"
+    assert m.feed("d") == "abd"                                  # it did not: released
+    assert m.feed("ab", final=True) == "ab" and not m.hit        # end of stream: nothing is held
+    m = _StopMatcher(["aab"])
+    assert m.feed("aaa") == "a" and m.feed("b") == "" and m.hit  # overlapping prefixes
+    m = _StopMatcher(["xy", "y"])
+    assert m.feed("ax") == "a" and m.feed("y") == "" and m.hit   # earliest match wins
