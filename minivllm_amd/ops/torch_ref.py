@@ -95,9 +95,10 @@ def store_kvcache(key: torch.Tensor, value: torch.Tensor, k_cache: torch.Tensor,
         slots, key, value = slots[keep], key[keep], value[keep]
     blk = torch.div(slots, bs, rounding_mode="floor")
     off = slots - blk * bs
-    if k_cache.dtype == torch.float8_e4m3fn:      # indexed writes go through the byte view
-        k_cache.view(torch.uint8)[blk, off] = key.to(k_cache.dtype).view(torch.uint8)
-        v_cache.view(torch.uint8)[blk, off] = value.to(v_cache.dtype).view(torch.uint8)
+    if k_cache.dtype == torch.float8_e4m3fn:      # indexed writes go through the byte view;
+        # values saturate at the format's largest finite number (448), as in the HIP kernel
+        k_cache.view(torch.uint8)[blk, off] = key.float().clamp(-448.0, 448.0).to(k_cache.dtype).view(torch.uint8)
+        v_cache.view(torch.uint8)[blk, off] = value.float().clamp(-448.0, 448.0).to(v_cache.dtype).view(torch.uint8)
         return
     k_cache[blk, off] = key.to(k_cache.dtype)
     v_cache[blk, off] = value.to(v_cache.dtype)
