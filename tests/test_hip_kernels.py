@@ -437,6 +437,16 @@ def test_qk_norm_rope_store_into_fp8_cache(hip, dtype, d):
         assert (g - w).abs().max() <= 0.13 * w.abs().max().clamp(min=1.0)
         assert (g != w).float().mean() < 0.02
     assert torch.equal(vc_h.float(), vc_r.to(FP8).float())      # v is copied, never recomputed
+    # out-of-range values saturate at the largest finite e4m3 number instead of becoming NaN
+    big = qkv.clone()
+    v0 = (hq + hkv) * d
+    big[3, v0] = 3000.0
+    big[3, v0 + 1] = -1.0e4
+    kc_s, vc_s = _logical_cache(nb, bs, hkv, d, FP8), _logical_cache(nb, bs, hkv, d, FP8)
+    hip.qk_norm_rope_store(big, pos, cs, qw, kw, 1e-6, hq, hkv, d, kc_s, vc_s, slots)
+    blk, off = int(slots[3]) // bs, int(slots[3]) % bs
+    row = vc_s[blk, off, 0].float()
+    assert row[0] == 448.0 and row[1] == -448.0 and not torch.isnan(vc_s.float()).any()
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
