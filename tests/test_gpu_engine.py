@@ -404,3 +404,23 @@ def test_fp8_kv_cache_engine_on_gpu(gpu):
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
     assert first >= 6 and same / total > 0.5, (first, same, total)
+
+
+def test_fp8_kv_cache_with_tp2_on_one_gpu(gpu):
+    """The fp8 cache under tensor parallelism: every rank stores and reads its own KV heads as
+    e4m3 (quantisation is per element, so the split does not change the cached values)."""
+    import os
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    prompts = _prompts(5, seed=31)
+    sp = SamplingParams(temperature=0, max_tokens=12, ignore_eos=True)
+    one = LLMEngine(_cfg(kv_cache_dtype="fp8"))
+    want = one.generate(prompts, sp)["token_ids"]
+    one.exit()
+    two = LLMEngine(_cfg(world_size=2, dist_backend="gloo", kv_cache_dtype="fp8",
+                         master_port=29500 + os.getpid() % 150, gpu_memory_utilization=0.3))
+    assert two.model_runner.kv_cache.dtype == torch.float8_e4m3fn
+    got = two.generate(prompts, sp)["token_ids"]
+    two.exit()
+    same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
+    total = sum(len(x) for x in want)
+    assert same / total > 0.9, (same, total)
