@@ -108,10 +108,10 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
             m["e2e"].observe(h.finished_at - h.submitted_at)
 
     def _reason(h: RequestHandle) -> Optional[str]:
-        return "stop" if getattr(h, "stop_text", None) is not None else h.finish_reason
+        return "stop" if h.stop_text is not None else h.finish_reason
 
     def _text(h: RequestHandle) -> str:
-        cut = getattr(h, "stop_text", None)
+        cut = h.stop_text
         return cut if cut is not None else engine.tokenizer.decode(h.token_ids,
                                                                    skip_special_tokens=True)
 

@@ -45,6 +45,8 @@ class RequestHandle:
         self.token_ids: List[int] = []           # everything generated so far
         self.num_prompt_tokens = 0
         self.finish_reason: Optional[str] = None
+        # set by a front end that cut the request short at a stop string: the text up to it
+        self.stop_text: Optional[str] = None
         self.error: Optional[BaseException] = None
         self.submitted_at = time.perf_counter()
         self.first_token_at: Optional[float] = None
