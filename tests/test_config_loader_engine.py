@@ -273,9 +273,11 @@ def test_fp8_kv_cache_on_the_cpu_path():
     sp = SamplingParams(temperature=0, max_tokens=10, ignore_eos=True)
     ref_eng = _engine(max_num_batched_tokens=48)
     want = ref_eng.generate(prompts, sp)["token_ids"]
+    bytes32 = ref_eng.model_runner.kv_block_bytes()
     ref_eng.exit()
     eng = _engine(max_num_batched_tokens=48, kv_cache_dtype="fp8")
     assert eng.model_runner.kv_cache.dtype == torch.float8_e4m3fn
+    assert eng.model_runner.kv_block_bytes() * 4 == bytes32        # one byte per value, not four
     got = eng.generate(prompts, sp)["token_ids"]
     assert eng.scheduler.block_manager.num_prefix_hits > 0
     eng.exit()
