@@ -198,13 +198,20 @@ class ModelRunner:
                  "gate_up": ([l.mlp.gate_up_proj.weight for l in layers], True),
                  "down": ([l.mlp.down_proj.weight for l in layers], False)}
         self.decode_gemm_choices = {}
+        self.mid_gemm_choices = {}
+        # decode batches are at most max_num_sequences rows: tune the buckets that can occur
+        rows = [b for b in hip.MID_ROW_BUCKETS if b // 2 < self.max_bs]
         for name, (ws, swiglu) in roles.items():
             self.decode_gemm_choices[name] = hip.tune_skinny_gemm(ws, swiglu)
+            if self.max_bs > hip.SKINNY_MAX_ROWS:
+                self.mid_gemm_choices[name] = hip.tune_mid_gemm(ws, swiglu, rows=rows)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         if self.rank == 0 and self.cfg.log_stats:
             print(f"[runner] decode GEMM choices (rows: library us, kernel us, use kernel): "
                   f"{self.decode_gemm_choices}", flush=True)
+            print(f"[runner] mid-batch GEMM choices (rows: library us, kernel us, (bn, splits, "
+                  f"nt)): {self.mid_gemm_choices}", flush=True)
 
     # ================================================================ buffers
     def _init_buffers(self) -> None:

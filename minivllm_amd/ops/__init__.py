@@ -82,22 +82,33 @@ def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scal
 
 
 def linear(x, weight, bias=None):
-    """``x @ weight.T (+ bias)``: the library GEMM, except for decode-sized GPU inputs of the
-    shapes where the hand-written weight-streaming kernel is faster."""
-    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 16:
+    """``x @ weight.T (+ bias)``: the library GEMM, except for decode-sized GPU inputs (<= 16
+    rows: skinny kernel; 17..256 rows: mid-batch kernel) of the shapes where the hand-written
+    weight-streaming kernels were measured to be faster on this machine."""
+    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 256:
         h = _hip()
-        if h.skinny_gemm_pays(x, weight):
-            return h.skinny_linear(x, weight, bias)
+        if x.shape[0] <= 16:
+            if h.skinny_gemm_pays(x, weight):
+                return h.skinny_linear(x, weight, bias)
+        else:
+            c = h.mid_gemm_choice(x, weight)
+            if c is not None:
+                return h.mid_linear(x, weight, bias, False, c[0], c[1], c[2])
     return F.linear(x, weight, bias)
 
 
 def swiglu_linear(x, weight, bias=None):
     """``silu(x @ Wg.T) * (x @ Wu.T)`` for the fused ``[Wg; Wu]`` weight: one kernel for
     decode-sized GPU inputs, otherwise GEMM + activation kernel."""
-    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 16:
+    if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 256:
         h = _hip()
-        if h.skinny_gemm_pays(x, weight, swiglu=True):
-            return h.skinny_linear(x, weight, bias, swiglu=True)
+        if x.shape[0] <= 16:
+            if h.skinny_gemm_pays(x, weight, swiglu=True):
+                return h.skinny_linear(x, weight, bias, swiglu=True)
+        else:
+            c = h.mid_gemm_choice(x, weight, swiglu=True)
+            if c is not None:
+                return h.mid_linear(x, weight, bias, True, c[0], c[1], c[2])
     return silu_and_mul(F.linear(x, weight, bias))
 
 

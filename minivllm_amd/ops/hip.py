@@ -69,6 +69,9 @@ _skinny_norm = _sig("mvl_skinny_norm_gemm", _c_void, _c_long, _c_void, _c_long, 
                     _c_float, _c_void, _c_void, _c_void, _c_long, _c_int, _c_int, _c_int,
                     _c_int, _c_int, _c_void)
 
+_mid = _sig("mvl_mid_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_void, _c_int,
+            _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void)
+
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 
 
@@ -494,6 +497,142 @@ def skinny_norm_linear(x: torch.Tensor, residual: Optional[torch.Tensor], eps: f
                         out.data_ptr(), out.stride(0), M, N, K, 1 if swiglu else 0, _dt(x),
                         _stream()), "skinny_norm_gemm")
     return out, r
+
+
+# ------------------------------------------- mid-batch weight-streaming GEMM (17..256 rows)
+MID_MAX_ROWS = 256
+_NUM_CUS = 256
+
+
+def mid_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
+    """Operands the mid-batch kernel takes: <= 256 rows with 16-byte aligned rows, K a multiple
+    of 64, N a multiple of 64 (SwiGLU: N/2 a multiple of 32), contiguous same-dtype weights."""
+    if x.dim() != 2 or x.shape[0] == 0 or x.shape[0] > MID_MAX_ROWS or x.dtype not in _DT:
+        return False
+    n, k = weight.shape
+    return (weight.dtype == x.dtype and weight.is_contiguous() and x.stride(1) == 1
+            and x.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and k % 64 == 0 and n % 64 == 0
+            and (not swiglu or (n // 2) % 32 == 0))
+
+
+def mid_row_tile(m: int) -> int:
+    return 64 if m <= 64 else 128 if m <= 128 else 256
+
+
+def mid_gemm_candidates(m: int, n: int, k: int, swiglu: bool = False):
+    """(bn, splits) pairs worth timing for this shape: both column-tile widths, with the K split
+    that brings the grid closest to one or two workgroups per CU."""
+    out = []
+    ksteps = k // 64
+    for bn in (128, 96, 64):
+        if n % bn or (swiglu and (n // 2) % (bn // 2)) or (bn == 96 and m <= 128):
+            continue
+        tiles = n // bn
+        seen = set()
+        for target in (_NUM_CUS, _NUM_CUS // 2, 2 * _NUM_CUS):
+            s = max(1, min(round(target / tiles), ksteps // 4 or 1, 16))
+            if s not in seen:
+                seen.add(s)
+                out.append((bn, s))
+    return out
+
+
+# (row bucket, N, K, swiglu) -> (bn, splits, nt) or None (= library); filled by tune_mid_gemm
+_MID_CHOICE: dict = {}
+MID_ROW_BUCKETS = (32, 64, 128, 256)
+
+
+def mid_row_bucket(m: int) -> int:
+    return 32 if m <= 32 else 64 if m <= 64 else 128 if m <= 128 else 256
+
+
+def mid_gemm_choice(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False):
+    """The tuned configuration for this call, or None when the library GEMM is to be used
+    (unmeasured shapes included: the kernel only runs where it was seen to win)."""
+    if x.dim() != 2 or x.shape[0] <= SKINNY_MAX_ROWS or x.shape[0] > MID_MAX_ROWS:
+        return None
+    n, k = weight.shape
+    c = _MID_CHOICE.get((mid_row_bucket(x.shape[0]), n, k, swiglu))
+    if c is None or not mid_gemm_ok(x, weight, swiglu):
+        return None
+    return c
+
+
+def mid_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               swiglu: bool = False, bn: int = 128, splits: int = 1, nt: bool = True,
+               bm: Optional[int] = None) -> torch.Tensor:
+    """``x @ weight.T (+ bias)`` (``swiglu``: ``silu(gate) * up`` of the fused weight) for up to
+    256 rows with the weight-streaming MFMA kernel; ``splits`` > 1 slices K over workgroups
+    (fp32 partial sums in a scratch buffer, summed by a second kernel)."""
+    M, K = x.shape
+    N = weight.shape[0]
+    if not mid_gemm_ok(x, weight, swiglu):
+        raise ValueError(f"mid_linear cannot take x {tuple(x.shape)} / weight {tuple(weight.shape)}")
+    bm = bm or mid_row_tile(M)
+    out = torch.empty((M, N // 2 if swiglu else N), dtype=x.dtype, device=x.device)
+    ws = (torch.empty(splits * M * N, dtype=torch.float32, device=x.device)
+          if splits > 1 else None)
+    _check(_mid(x.data_ptr(), x.stride(0), weight.data_ptr(),
+                bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
+                ws.data_ptr() if ws is not None else None, M, N, K, int(swiglu), bm, bn, splits,
+                int(nt), _dt(x), _stream()), "mid_gemm")
+    return out
+
+
+def _graph_time_ms(fn, x, weights, reps: int) -> float:
+    """Milliseconds per call of ``fn(x, w)`` cycling through ``weights`` (cold reads), measured
+    on three replays of a captured graph (no launch gaps)."""
+    for w in weights[:2]:
+        fn(x, w)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, capture_error_mode="thread_local"):
+        for _ in range(reps):
+            for w in weights:
+                fn(x, w)
+    g.replay()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(3):
+        g.replay()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / (3 * reps * len(weights))
+
+
+def tune_mid_gemm(weights, swiglu: bool = False, rows=MID_ROW_BUCKETS,
+                  margin: float = 0.97) -> dict:
+    """For one projection (same-shaped matrices of several layers, cycled so that reads stay
+    cold): time the library GEMM (+ activation kernel) against every candidate configuration
+    of the mid-batch kernel at the top of each row bucket and record the winner.  Returns
+    {rows: (library us, best kernel us or None, (bn, splits, nt) or None)}."""
+    import torch.nn.functional as F
+    weights = list(weights)
+    n, k = weights[0].shape
+    dtype, dev = weights[0].dtype, weights[0].device
+    out = {}
+    if not mid_gemm_ok(torch.zeros(64, k, dtype=dtype, device=dev), weights[0], swiglu) \
+            or n * k * 2 < (1 << 20):
+        return out
+    reps = max(1, min(4, -(-(640 << 20) // (n * k * 2 * len(weights)))))
+
+    def lib(x, w):
+        y = F.linear(x, w)
+        return silu_and_mul(y) if swiglu else y
+
+    for m in rows:
+        x = torch.randn(m, k, dtype=dtype, device=dev)
+        t_lib = _graph_time_ms(lib, x, weights, reps)
+        best, t_best = None, t_lib * margin
+        for bn, sp in mid_gemm_candidates(m, n, k, swiglu):
+            t = _graph_time_ms(lambda xx, w: mid_linear(xx, w, None, swiglu, bn, sp, True),
+                               x, weights, reps)
+            if t < t_best:
+                best, t_best = (bn, sp, True), t
+        _MID_CHOICE[(mid_row_bucket(m), n, k, swiglu)] = best
+        out[m] = (round(t_lib * 1e3, 1), round(t_best * 1e3, 1) if best else None, best)
+    return out
 
 
 # -------------------------------------------------------------------- sampler

@@ -389,6 +389,93 @@ def test_skinny_gemm_swiglu(hip, dtype, M):
     assert not hip.skinny_gemm_ok(torch.empty(17, K, device=DEV, dtype=dtype), w)
 
 
+# ------------------------------------------------- mid-batch weight-streaming GEMM
+# projection shapes (N, K): Qwen3-0.6B / 8B / 32B at TP=1 and the per-rank 8B / 32B shapes at TP=8
+_MID_SHAPES = [(4096, 1024), (1024, 2048), (1024, 3072),                    # 0.6B qkv / o / down
+               (6144, 4096), (4096, 4096), (4096, 12288),                   # 8B
+               (10240, 5120), (5120, 8192), (5120, 25600),                  # 32B
+               (768, 4096), (4096, 512), (4096, 1536), (1280, 5120), (5120, 3200)]   # TP=8 ranks
+
+
+def _mid_check(hip, dtype, M, N, K, bn, splits, swiglu=False, bias=False, strided=False):
+    torch.manual_seed(31)
+    if strided:
+        x = torch.randn(M + 3, K + 64, device=DEV, dtype=dtype)[:M, :K]
+    else:
+        x = torch.randn(M, K, device=DEV, dtype=dtype)
+    w = (torch.randn(N, K, device=DEV) * 0.03).to(dtype)
+    b = torch.randn(N, device=DEV, dtype=dtype) if bias else None
+    y = x.float() @ w.float().T
+    if bias:
+        y = y + b.float()
+    want = torch.nn.functional.silu(y[:, :N // 2]) * y[:, N // 2:] if swiglu else y
+    for nt in (True, False):
+        got = hip.mid_linear(x, w, b, swiglu=swiglu, bn=bn, splits=splits, nt=nt)
+        assert got.shape == want.shape
+        close(got, want, dtype, 4)
+
+
+@pytest.mark.parametrize("M", [17, 32, 64, 128, 256])
+@pytest.mark.parametrize("N,K", _MID_SHAPES)
+def test_mid_gemm_shapes(hip, M, N, K):
+    """Every projection shape x row count vs the fp32 product, with the first candidate
+    configuration the tuner would try plus a deliberately uneven K split."""
+    dtype = torch.bfloat16
+    cands = hip.mid_gemm_candidates(M, N, K)
+    assert cands
+    bn, sp = cands[0]
+    _mid_check(hip, dtype, M, N, K, bn, sp)
+    _mid_check(hip, dtype, M, N, K, 64, 3)           # k-steps not divisible by the split count
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [19, 64, 100, 128, 200, 256])
+@pytest.mark.parametrize("bn,splits", [(128, 1), (64, 1), (128, 4), (64, 7), (96, 1), (96, 3)])
+def test_mid_gemm_tiles(hip, dtype, M, bn, splits):
+    """Each row tile x column tile x split mode, with bias and strided activations."""
+    if bn == 96 and M <= 128:
+        pytest.skip("96-column tiles exist for the 256-row tile only")
+    _mid_check(hip, dtype, M, 1536, 2048, bn, splits, bias=True, strided=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [17, 64, 128, 256])
+@pytest.mark.parametrize("I,K", [(3072, 1024), (12288, 4096), (1536, 4096), (3200, 5120)])
+@pytest.mark.parametrize("bn,splits", [(128, 1), (64, 2), (96, 1), (96, 2)])
+def test_mid_gemm_swiglu(hip, dtype, M, I, K, bn, splits):
+    """Fused [gate; up] weight -> silu(gate) * up, direct epilogue and through the K-split
+    reduce kernel (3200 = 25 x 128: the Qwen3-32B intermediate size per TP=8 rank)."""
+    if (2 * I) % bn or I % (bn // 2) or (bn == 96 and M <= 128):
+        pytest.skip("tile does not divide the intermediate size / no such tile")
+    _mid_check(hip, dtype, M, 2 * I, K, bn, splits, swiglu=True, bias=(M == 64))
+
+
+def test_mid_gemm_k_structure(hip):
+    """Exact small-integer data: every k position of every row must land in the right
+    accumulator (a swapped chunk or a wrong XOR shows up as an integer mismatch)."""
+    M, N, K = 256, 256, 512
+    x = torch.randint(-2, 3, (M, K), device=DEV).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (N, K), device=DEV).to(torch.bfloat16)
+    # asymmetric: scale w rows and x columns so that transposes / k-permutations cannot cancel
+    w[::3] *= 2
+    x[:, ::5] *= 2
+    want = x.float() @ w.float().T
+    for bn in (64, 128):
+        for sp in (1, 2):
+            got = hip.mid_linear(x, w, bn=bn, splits=sp)
+            assert torch.equal(got.float(), want.to(torch.bfloat16).float())
+
+
+def test_mid_gemm_rejects(hip):
+    w = torch.zeros(1024, 1000, device=DEV, dtype=torch.bfloat16)
+    assert not hip.mid_gemm_ok(torch.zeros(64, 1000, device=DEV, dtype=torch.bfloat16), w)
+    w = torch.zeros(1024, 1024, device=DEV, dtype=torch.bfloat16)
+    assert not hip.mid_gemm_ok(torch.zeros(257, 1024, device=DEV, dtype=torch.bfloat16), w)
+    assert hip.mid_gemm_ok(torch.zeros(256, 1024, device=DEV, dtype=torch.bfloat16), w)
+    with pytest.raises(ValueError):
+        hip.mid_linear(torch.zeros(300, 1024, device=DEV, dtype=torch.bfloat16), w)
+
+
 # ------------------------------------------------------------------ fp8 KV cache
 FP8 = torch.float8_e4m3fn
 
