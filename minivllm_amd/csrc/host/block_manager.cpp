@@ -183,11 +183,21 @@ long mvl_bm_allocate(void* mp, const int32_t* tokens, long n_tokens, int32_t* ou
     return cached >= n_tokens ? n_tokens - 1 : cached;
 }
 
-void mvl_bm_deallocate(void* mp, const int32_t* table, int n) {
+// Blocks at table index >= first_invalid hold KV that was never (completely) written: one
+// that nobody else holds loses its prefix-cache identity.  first_invalid = n: all are valid.
+void mvl_bm_deallocate(void* mp, const int32_t* table, int n, int first_invalid) {
     Manager& m = *(Manager*)mp;
     for (int i = n - 1; i >= 0; --i) {
         Block& b = m.blocks[table[i]];
-        if (--b.ref_count == 0) m.push_free(table[i]);      // keeps its hash: revivable
+        if (--b.ref_count == 0) {
+            if (i >= first_invalid && b.hashed) {
+                auto it = m.by_hash.find(b.hash);
+                if (it != m.by_hash.end() && it->second == table[i]) m.by_hash.erase(it);
+                b.hashed = false;
+                b.tokens.clear();
+            }
+            m.push_free(table[i]);                          // a valid block keeps its hash: revivable
+        }
     }
 }
 

@@ -136,12 +136,25 @@ class BlockManager:
         if seq.num_cached_tokens >= seq.num_tokens:
             seq.num_cached_tokens = seq.num_tokens - 1
 
-    def deallocate(self, seq: Sequence) -> None:
-        for block_id in reversed(seq.block_table):
+    def deallocate(self, seq: Sequence, num_valid_tokens: Optional[int] = None) -> None:
+        """Give the sequence's blocks back.  ``num_valid_tokens``: only that many leading
+        tokens have their KV in the cache (a request dropped in the middle of its prefill,
+        or whose step failed): a block beyond them that nobody else holds loses its prefix-cache
+        identity, so that a later request with the same prompt recomputes it instead of
+        attending to KV that was never written."""
+        first_invalid = (len(seq.block_table) if num_valid_tokens is None
+                         else max(num_valid_tokens, 0) // self.block_size)
+        for i in range(len(seq.block_table) - 1, -1, -1):
+            block_id = seq.block_table[i]
             block = self.blocks[block_id]
             block.ref_count -= 1
             assert block.ref_count >= 0
             if block.ref_count == 0:
+                if i >= first_invalid and block.hash != -1:
+                    if self.hash_to_block_id.get(block.hash) == block_id:
+                        del self.hash_to_block_id[block.hash]
+                    block.hash = -1
+                    block.token_ids = []
                 self._release_block(block_id)
         seq.block_table = []
         seq.num_cached_tokens = 0
@@ -212,7 +225,7 @@ def _host_lib():
         lib.mvl_bm_num_free.argtypes = [vp]
         lib.mvl_bm_allocate.restype = ctypes.c_long
         lib.mvl_bm_allocate.argtypes = [vp, vp, ctypes.c_long, vp]
-        lib.mvl_bm_deallocate.argtypes = [vp, vp, ctypes.c_int]
+        lib.mvl_bm_deallocate.argtypes = [vp, vp, ctypes.c_int, ctypes.c_int]
         lib.mvl_bm_append.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long, vp]
         lib.mvl_bm_stats.argtypes = [vp, ctypes.POINTER(ctypes.c_long)]
         lib.mvl_bm_ref_count.argtypes = [vp, ctypes.c_int]
@@ -285,10 +298,13 @@ class NativeBlockManager:
         seq.block_table = table.tolist()
         seq.num_cached_tokens = int(cached)
 
-    def deallocate(self, seq: Sequence) -> None:
+    def deallocate(self, seq: Sequence, num_valid_tokens: Optional[int] = None) -> None:
+        """See :meth:`BlockManager.deallocate`."""
         if seq.block_table:
             table = np.asarray(seq.block_table, dtype=np.int32)
-            self._lib.mvl_bm_deallocate(self._h, table.ctypes.data, len(table))
+            first_invalid = (len(table) if num_valid_tokens is None
+                             else max(num_valid_tokens, 0) // self.block_size)
+            self._lib.mvl_bm_deallocate(self._h, table.ctypes.data, len(table), first_invalid)
         seq.block_table = []
         seq.num_cached_tokens = 0
 

@@ -256,22 +256,34 @@ class Scheduler:
         self.waiting.appendleft(seq)
         self.num_preemptions += 1
 
-    def abort(self, seq: Sequence) -> bool:
+    def abort(self, seq: Sequence, step_failed: bool = False) -> bool:
         """Drop a request wherever it is queued (a client went away): its KV blocks return to
-        the pool (full blocks stay in the prefix cache).  False when it had already left."""
-        found = False
+        the pool and the full blocks whose KV was computed stay in the prefix cache.  Blocks
+        whose hash was published at admission but whose KV does not exist yet (the prompt was
+        still being prefilled in chunks) are withdrawn from the prefix cache.  ``step_failed``:
+        the step that last carried the sequence raised before completing, so nothing that step
+        was to write counts as computed.  False when the request had already left."""
+        found = in_prefill = False
         for q in (self.waiting, self.prefilling, self.running):
             for i, s in enumerate(q):
                 if s is seq:
                     del q[i]
                     found = True
+                    in_prefill = q is self.prefilling
                     break
         if not found:
             return False
         self._decode_batch = None
-        seq.prefill_end = None
         if seq.block_table:
-            self.block_manager.deallocate(seq)
+            if in_prefill or seq.prefill_end is not None:
+                # prefill incomplete, or its step never reached postprocess
+                valid = 0 if step_failed else seq.num_cached_tokens
+            elif step_failed:
+                valid = seq.num_tokens - 1       # the newest token's KV slot may be unwritten
+            else:
+                valid = None
+            self.block_manager.deallocate(seq, valid)
+        seq.prefill_end = None
         seq.status = SequenceStatus.FINISHED
         return True
 

@@ -252,8 +252,9 @@ class AsyncLLMEngine:
             h._finish("stop" if eos else "length")
 
     def _fail_all(self, err: BaseException) -> None:
+        # the step raised: whatever KV it was writing does not count as computed
         for h in list(self._active.values()):
-            self.engine.scheduler.abort(h._seq)
+            self.engine.scheduler.abort(h._seq, step_failed=True)
             h._finish("error", err)
         self._active.clear()
 

@@ -14,7 +14,7 @@ void* mvl_bm_create(int num_blocks, int block_size);
 void mvl_bm_destroy(void* m);
 int mvl_bm_num_free(void* m);
 long mvl_bm_allocate(void* m, const int32_t* tokens, long n_tokens, int32_t* out_table);
-void mvl_bm_deallocate(void* m, const int32_t* table, int n);
+void mvl_bm_deallocate(void* m, const int32_t* table, int n, int first_invalid);
 int mvl_bm_append(void* m, int n_table, int last, int before_last, long n_tokens,
                   const int32_t* last_block_tokens);
 void mvl_bm_stats(void* m, long* out);
@@ -82,7 +82,7 @@ int main(int argc, char** argv) {
             if (added == -2) {                                   // no block: preempt this one
                 CHECK(mvl_bm_num_free(bm) == 0);
                 s.tokens.pop_back();
-                mvl_bm_deallocate(bm, s.table.data(), (int)s.table.size());
+                mvl_bm_deallocate(bm, s.table.data(), (int)s.table.size(), (int)s.table.size());
                 s = std::move(live.back());
                 live.pop_back();
                 continue;
@@ -91,7 +91,7 @@ int main(int argc, char** argv) {
             CHECK((long)s.table.size() == (n + BS - 1) / BS);
         } else if (!live.empty()) {                              // finish
             const size_t k = rng() % live.size();
-            mvl_bm_deallocate(bm, live[k].table.data(), (int)live[k].table.size());
+            mvl_bm_deallocate(bm, live[k].table.data(), (int)live[k].table.size(), (int)live[k].table.size());
             live[k] = std::move(live.back());
             live.pop_back();
         }
@@ -110,7 +110,7 @@ int main(int argc, char** argv) {
         CHECK(st[0] == NB && st[1] == NB - used && st[2] == used && st[1] == mvl_bm_num_free(bm));
         CHECK(st[4] <= st[5] && st[3] <= NB);
     }
-    for (Seq& s : live) mvl_bm_deallocate(bm, s.table.data(), (int)s.table.size());
+    for (Seq& s : live) mvl_bm_deallocate(bm, s.table.data(), (int)s.table.size(), (int)s.table.size());
     CHECK(mvl_bm_num_free(bm) == NB);
     mvl_bm_destroy(bm);
     std::printf("ok: %d operations, %ld prompt tokens served from the prefix cache\n", steps,

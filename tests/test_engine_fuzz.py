@@ -116,3 +116,25 @@ def test_fp8_cache_under_the_same_stress(seed):
         total += len(got)
     assert same / total > 0.6, (same, total)
     eng.exit()
+
+
+def test_retry_after_abort_mid_chunked_prefill_matches_a_plain_run():
+    """A prompt longer than the token budget is dropped after its first chunk (a client
+    time-out) and submitted again: the retry must not attend to blocks whose KV the aborted
+    request never wrote."""
+    rng = np.random.default_rng(7)
+    prompt = rng.integers(0, 300, size=130).tolist()            # 3 chunks of 48 tokens
+    sp = SamplingParams(temperature=0, max_tokens=12, ignore_eos=True)
+    ref = _engine()
+    want = ref.generate([prompt], sp)["token_ids"][0]
+    ref.exit()
+    eng = _engine()
+    first = eng.add_prompt(prompt, sp)
+    eng.step()                                                  # first chunk only
+    assert list(eng.scheduler.prefilling) == [first]
+    assert eng.scheduler.abort(first)
+    got = eng.generate([prompt], sp)["token_ids"][0]
+    assert got == want
+    bm = eng.scheduler.block_manager
+    assert bm.num_free_blocks == bm.num_blocks
+    eng.exit()

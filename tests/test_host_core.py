@@ -354,6 +354,62 @@ def test_abort_removes_a_request_from_any_queue_and_returns_its_blocks():
     assert a.status == SequenceStatus.FINISHED
 
 
+@pytest.mark.parametrize("native", [False, True])
+def test_deallocate_withdraws_blocks_whose_kv_was_never_written(native):
+    """Hashes are published at admission; a request dropped before its KV exists must not
+    leave them behind (both allocator implementations)."""
+    from minivllm_amd.engine.block_manager import make_block_manager, _host_lib
+    if native and _host_lib() is None:
+        pytest.skip("_host_core.so not built")
+    bm = make_block_manager(16, BS, native=native)
+    prompt = list(range(100, 100 + 3 * BS + 2))                 # 3 full blocks + a partial one
+    a = seq(prompt)
+    bm.allocate(a)
+    assert a.num_cached_tokens == 0
+    bm.deallocate(a, num_valid_tokens=BS + 1)                   # only the first block was computed
+    assert bm.num_free_blocks == 16
+    b = seq(prompt)
+    bm.allocate(b)
+    assert b.num_cached_tokens == BS                            # blocks 1 and 2 are recomputed
+    bm.deallocate(b)                                            # everything computed this time
+    c = seq(prompt)
+    bm.allocate(c)
+    assert c.num_cached_tokens == 3 * BS
+    # a block somebody else still holds keeps its identity
+    d = seq(prompt)
+    bm.allocate(d)
+    bm.deallocate(c, num_valid_tokens=0)
+    e = seq(prompt)
+    bm.allocate(e)
+    assert e.num_cached_tokens == 3 * BS
+    for s in (d, e):
+        bm.deallocate(s)
+    assert bm.num_free_blocks == 16
+
+
+def test_abort_mid_prefill_leaves_no_uncomputed_blocks_in_the_prefix_cache():
+    sch = make_sched(blocks=32, max_seqs=2, max_tokens=8, chunked=True)     # 2 blocks per step
+    prompt = list(range(500, 500 + 5 * BS))
+    a = seq(prompt, max_tokens=4)
+    sch.add_sequence(a)
+    batch, is_prefill = sch.schedule()
+    assert is_prefill and a.prefill_end == 8 and list(sch.prefilling) == [a]
+    sch.postprocess(batch, [0])                                 # first chunk (2 blocks) computed
+    assert sch.abort(a)
+    b = seq(prompt, max_tokens=4)
+    sch.add_sequence(b)
+    sch.schedule()
+    assert b.num_cached_tokens == 8                             # not 16: blocks 2, 3 never existed
+    # a step that raised: even the chunk it was writing does not count
+    sch.abort(b, step_failed=True)
+    c = seq(prompt, max_tokens=4)
+    sch.add_sequence(c)
+    sch.schedule()
+    # conservative: blocks b held alone are all withdrawn (some of its cache hits may have
+    # been blocks another request of the same failed step was only about to write)
+    assert c.num_cached_tokens == 0
+
+
 def test_small_prefill_steps_wait_for_company_but_not_forever():
     import time
     sch = Scheduler(8, 64, 64, BS, 999, min_prefill_tokens=16, max_prefill_delay_s=0.05)
