@@ -29,6 +29,8 @@ from fastapi.responses import JSONResponse, Response, StreamingResponse
 from minivllm_amd.sampling_parameters import SamplingParams
 from minivllm_amd.serve.async_engine import AsyncLLMEngine, RequestHandle
 
+MAX_SEQUENCES_PER_REQUEST = 256          # prompts x n of one /v1/completions call
+
 
 class _TextStream:
     """Incremental detokenisation: text is released only up to the last complete character
@@ -264,7 +266,9 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
     @app.get("/metrics")
     async def metrics():
         from prometheus_client import generate_latest
-        st = engine.stats()
+        # a data-parallel front end asks its replica processes and waits for the answers:
+        # off the event loop
+        st = await asyncio.get_running_loop().run_in_executor(None, engine.stats)
         m["running"].set(st["running"]); m["waiting"].set(st["waiting"])
         m["kv_free"].set(st["kv_blocks_free"])
         m["prefill_tok_s"].set(st["prefill_tok_s"]); m["decode_tok_s"].set(st["decode_tok_s"])
@@ -277,6 +281,9 @@ def create_app(engine: AsyncLLMEngine, model_name: str = "minivllm"):
         loop = asyncio.get_running_loop()
         rid, created = f"cmpl-{uuid.uuid4().hex}", int(time.time())
         n = _n(body)
+        if len(prompts) * n > MAX_SEQUENCES_PER_REQUEST:
+            raise HTTPException(400, f"a request may ask for at most {MAX_SEQUENCES_PER_REQUEST} "
+                                     f"sequences (prompts x n), got {len(prompts) * n}")
         hs = [engine.submit(p, sp, loop=loop) for p in prompts for _ in range(n)]
         if body.get("stream"):
             def chunk(i, text, toks, reason):

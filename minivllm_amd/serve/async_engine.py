@@ -136,6 +136,7 @@ class AsyncLLMEngine:
         self._startup_error: Optional[BaseException] = None
         self._thread: Optional[threading.Thread] = None
         self.engine = None
+        self._stats_snapshot: dict = {}
         self.requests_finished = 0
         self.requests_aborted = 0
         if start:
@@ -200,6 +201,12 @@ class AsyncLLMEngine:
         return self.submit(prompt, sampling_params).result(timeout)
 
     def stats(self) -> dict:
+        """The counters as of the engine thread's last step.  Other threads never touch the
+        scheduler or the (native) block manager themselves: the engine thread takes the
+        snapshot between steps and readers get a copy of it."""
+        return dict(self._stats_snapshot)
+
+    def _snapshot_stats(self) -> None:                     # engine thread only
         eng = self.engine
         sch = eng.scheduler
         out = eng.stats.as_dict()
@@ -209,7 +216,7 @@ class AsyncLLMEngine:
                    kv_blocks_free=sch.block_manager.num_free_blocks,
                    kv_blocks=sch.block_manager.num_blocks,
                    prefix_hits=sch.block_manager.num_prefix_hits)
-        return out
+        self._stats_snapshot = out                         # one reference assignment
 
     # ------------------------------------------------------- engine thread
     def _handle(self, item) -> Optional[bool]:
@@ -228,6 +235,7 @@ class AsyncLLMEngine:
             if h._seq is not None and self._active.pop(h._seq.seq_id, None) is not None:
                 self.engine.scheduler.abort(h._seq)
                 self.requests_aborted += 1
+                self._snapshot_stats()
                 h._finish("abort")
         elif kind == "stop":
             return bool(item[1])
@@ -241,6 +249,7 @@ class AsyncLLMEngine:
                 start = seq.num_prompt_tokens + h._sent
                 h._sent = n
                 h._emit(seq.token_ids[start:seq.num_tokens])
+        done = []
         for seq_id, _ in finished:
             h = self._active.pop(seq_id, None)
             if h is None:
@@ -249,7 +258,11 @@ class AsyncLLMEngine:
             eos = ((not seq.ignore_eos and seq.last_token == self.engine.scheduler.eos)
                    or seq.last_token in seq.stop_token_ids)
             self.requests_finished += 1
-            h._finish("stop" if eos else "length")
+            done.append((h, "stop" if eos else "length"))
+        # a client that sees its request complete must also see it in the counters
+        self._snapshot_stats()
+        for h, reason in done:
+            h._finish(reason)
 
     def _fail_all(self, err: BaseException) -> None:
         # the step raised: whatever KV it was writing does not count as computed
@@ -267,6 +280,7 @@ class AsyncLLMEngine:
             self._stopped.set()
             self._ready.set()
             return
+        self._snapshot_stats()
         self._ready.set()
         eng, st = self.engine, self.engine.stats
         stopping, drain = False, True
@@ -288,6 +302,7 @@ class AsyncLLMEngine:
                     except queue.Empty:
                         item = None
                 if eng.is_finished() or (stopping and not drain):
+                    self._snapshot_stats()
                     continue
                 t0 = time.perf_counter()
                 try:

@@ -205,7 +205,10 @@ class DataParallelAsyncEngine:
             q.put(("stats", sid))
         import time
         deadline = time.monotonic() + timeout
-        while len(box) < self.dp_size and time.monotonic() < deadline and not self._stopped.is_set():
+        # only replicas that are alive can answer: a dead one must not hold every caller for
+        # the full timeout
+        while (len(box) < self.dp_size - len(self._dead) and time.monotonic() < deadline
+               and not self._stopped.is_set()):
             time.sleep(0.002)
         with self._lock:
             self._stats_wait.pop(sid, None)
@@ -264,15 +267,22 @@ class DataParallelAsyncEngine:
                 h._finish("error", err)
 
     def _dispatch(self) -> None:
+        import time
         stopped = 0
+        next_reap = time.monotonic() + 0.5
         while stopped < self.dp_size:
+            # liveness is checked on a timer, not only when the queue runs dry: with other
+            # replicas streaming tokens the queue is rarely empty
+            if time.monotonic() >= next_reap:
+                next_reap = time.monotonic() + 0.5
+                if not self._stopped.is_set():
+                    self._reap_dead_replicas()
+                    if len(self._dead) == self.dp_size:
+                        break
             try:
                 msg = self._outq.get(timeout=0.5)
             except queue.Empty:
                 if self._stopped.is_set():
-                    break
-                self._reap_dead_replicas()
-                if len(self._dead) == self.dp_size:
                     break
                 continue
             kind = msg[0]

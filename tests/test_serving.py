@@ -147,6 +147,8 @@ def test_http_api(server_engine, offline_tokens):
     assert client.post("/v1/completions", content=b"{not json").status_code == 400
     assert client.post("/v1/chat/completions", json=[1, 2]).status_code == 400
     assert client.post("/v1/completions", json={"prompt": "x", "max_tokens": 0}).status_code == 400
+    assert client.post("/v1/completions", json={"prompt": [[1, 2]] * 40, "n": 8,
+                                                "max_tokens": 1}).status_code == 400   # 320 sequences
     assert client.post("/v1/completions",
                        json={"prompt": list(range(1, 95)), "max_tokens": 50}).status_code == 400
     # stop strings: the text ends before the first one, the request is cut short
@@ -248,6 +250,9 @@ def test_a_dying_replica_fails_its_requests_and_the_other_keeps_serving(offline_
         with pytest.raises(RuntimeError):
             a.result(timeout=60)
         assert a.finish_reason == "error" and len(b.result(timeout=120)) == 80
+        t0 = time.monotonic()
+        st = eng.stats()                                      # only the survivor can answer
+        assert time.monotonic() - t0 < 5.0 and len(st["replicas"]) == 1
         got = [eng.generate(p, sp, timeout=120) for p in _prompts(3)]   # routed to the survivor
         assert got == offline_tokens[:3]
 
