@@ -18,17 +18,19 @@ sum(len(prompt)) tokens, a decode step one token per running sequence.
 Each timed region is bracketed by device synchronise + barrier on every rank and the elapsed
 time is the MAX over ranks.  Rank 0 prints ONE JSON line.
 
-With N > 1 two deployments of the same N GPUs are measured:
+With N > 1 the headline is the reference's own (and only) parallelism, tensor parallelism
+(reference: src/myvllm/engine/model_runner.py:20-25, layers/linear.py:195-221):
 
-* data parallel (the headline ``value``): N single-GPU replicas, each serving its own batch of
-  B sequences (weak scaling, global batch N x B).  Qwen3-8B fits one 288 GB GPU many times
-  over, so the throughput-optimal MI355X deployment does not shard it: no xGMI collective sits
-  on the critical path and every GEMM keeps its full width.
-* tensor parallel (``tensor_parallel`` in the JSON): ONE engine sharded over the N GPUs (RCCL
-  all-reduce over xGMI inside the hipGraph-captured decode step), global batch B (strong
-  scaling) - the latency-oriented deployment and the one a model too large for one GPU needs.
-  ``tensor_parallel_p2p_allreduce`` repeats it with decode-sized all-reduces done by the
+* ``value`` / ``ms_per_step`` / ``prefill_tok_s``: ONE engine sharded over the N GPUs (RCCL
+  all-reduce over xGMI inside the hipGraph-captured decode step), global batch B whatever N is
+  (strong scaling).  The JSON records the process-group size the engine really saw, whether
+  the decode graphs were captured and whether the peer-to-peer all-reduce kernel was active.
+* ``tensor_parallel_p2p_allreduce``: the same with decode-sized all-reduces done by the
   peer-to-peer kernel of ``parallel/custom_allreduce.py`` instead of RCCL.
+* ``qwen3_32b_tp8_32k_prefill`` (N = 8 only): Qwen3-32B sharded over the 8 GPUs, 32768-token
+  prompts - the long-context configuration.
+* ``data_parallel_replicas``: a side result, NOT the reference's parallelism - N single-GPU
+  replicas each serving its own batch of B sequences (weak scaling, global batch N x B).
 
 Under a launcher each rank's bench.py process is only an orchestrator: every phase runs in a
 child process of its own (fresh HIP context, fresh rendezvous store, a time limit), so a phase
@@ -53,7 +55,8 @@ import torch
 from minivllm_amd.config import EngineConfig, model_preset
 from minivllm_amd.parallel.group import env_rank_world
 
-PHASE_PORT_OFFSET = {"dp": 101, "tp": 202, "tpc": 303}
+PHASE_PORT_OFFSET = {"dp": 101, "tp": 202, "tpc": 303, "l32k": 404}
+LONG_CONTEXT = dict(model="qwen3-32b", seq_len=32768, prefill_tokens=32768, batch=8)
 
 
 def make_config(args, model_name: str, world: int) -> EngineConfig:
@@ -125,9 +128,13 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
     def prompts(n, length):
         return rng.integers(0, vocab, size=(n, length)).tolist()
 
-    res = {"init_s": round(init_s, 1), "kv_blocks": eng.model_runner.num_kv_blocks}
-    if not replicas and world > 1:
+    res = {"init_s": round(init_s, 1), "kv_blocks": eng.model_runner.num_kv_blocks,
+           "hipgraph_captured": bool(eng.model_runner.graphs)}
+    if not replicas:
         from minivllm_amd.parallel import group as pg
+        res["tp_world_size_seen"] = (dist.get_world_size(pg.tp_group())
+                                     if dist.is_initialized() and world > 1 else 1)
+        res["dist_backend"] = dist.get_backend(pg.tp_group()) if dist.is_initialized() and world > 1 else None
         res["p2p_allreduce"] = pg.custom_all_reduce() is not None
 
     # ------------------------------------------------------------ prefill phase
@@ -138,7 +145,7 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
             eng.add_prompt(p, sp)
         for _ in range(W):
             _, n, is_prefill = eng.step()
-            assert is_prefill and n == per_step * S
+            assert is_prefill
         runner.call("timer_start")
         tokens = 0
         for _ in range(K):
@@ -146,16 +153,17 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
             assert is_prefill
             tokens += n
         dt = runner.call("timer_stop")
-        assert eng.is_finished()
+        while not eng.is_finished():             # a budget that the prompt length does not divide
+            eng.step()
         res.update(prefill_tok_s=tokens / dt, prefill_ms_per_step=dt / K * 1e3,
-                   prefill_tokens_per_step=per_step * S)
+                   prefill_tokens_per_step=tokens // K)
 
     # ------------------------------------------------------------- decode phase
     if args.mode in ("both", "decode"):
         sp = SamplingParams(temperature=0.6, max_tokens=W + K + 1, ignore_eos=True)
         for p in prompts(B, S):
             eng.add_prompt(p, sp)
-        while eng.scheduler.waiting:             # untimed: prefill all B prompts
+        while eng.scheduler.waiting or eng.scheduler.prefilling:   # untimed: prefill all B prompts
             _, _, is_prefill = eng.step()
             assert is_prefill
         for _ in range(W):
@@ -185,6 +193,11 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
     """Body of one phase.  Returns {'main': ..., 'second': ...} on rank 0, None elsewhere."""
     torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ["MINIVLLM_KEEP_PG"] = "1"         # two engines in a row share one process group
+    if phase == "l32k":                          # Qwen3-32B, 32768-token prompts, few steps
+        args = argparse.Namespace(**vars(args))
+        for k, v in LONG_CONTEXT.items():
+            setattr(args, k, v)
+        args.steps, args.warmup, args.second_model = min(args.steps, 4), 1, ""
     models = [args.model] + ([args.second_model] if args.second_model
                              and args.second_model != args.model and phase != "tpc" else [])
     if phase == "dp" and (world > 1 or os.environ.get("MINIVLLM_FORCE_PG") == "1"):
@@ -195,7 +208,7 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
         addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, init_method=f"tcp://{addr}:{os.environ['MASTER_PORT']}",
                                 rank=rank, world_size=world, **kw)
-    out = [bench_model(args, m, rank, world, replicas=(phase not in ("tp", "tpc")))
+    out = [bench_model(args, m, rank, world, replicas=(phase not in ("tp", "tpc", "l32k")))
            for m in models]
     import torch.distributed as dist
     if dist.is_initialized():                    # kept alive across the engines of this phase
@@ -205,7 +218,10 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
             pass
     if rank != 0:
         return None
-    return {"main": out[0], "second": out[1] if len(out) > 1 else None}
+    res = {"main": out[0], "second": out[1] if len(out) > 1 else None}
+    if phase == "l32k":
+        res["config"] = dict(LONG_CONTEXT, steps=args.steps, warmup=args.warmup)
+    return res
 
 
 def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int):
@@ -221,8 +237,9 @@ def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int):
     if phase == "tpc":                           # TP again, all-reduce by the peer-to-peer kernel
         env["MINIVLLM_CUSTOM_AR"] = "1"
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
-    # the tensor-parallel phases are side results: a stuck one must not hold the headline back long
-    limit = args.phase_timeout if phase == "dp" else min(args.phase_timeout, 360)
+    # the headline (tp) and the long-context phase get the full limit; side results less, so
+    # that a stuck one does not hold the JSON line back long
+    limit = args.phase_timeout if phase in ("tp", "l32k") else min(args.phase_timeout, 360)
     t0 = time.time()
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     stdout = None
@@ -273,11 +290,13 @@ def headline(m):
             round(m.get("decode_ms_per_step", m.get("prefill_ms_per_step")), 3))
 
 
-def assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common):
+def assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common, long_ctx=None):
     """The one JSON object of an N > 1 run from the phase results (each a dict from
     ``spawn_phase``, ``{'error': ...}`` or None when the phase was skipped).  Returns
-    (object, whether any phase delivered a number).  Headline = data parallel; if that phase
-    failed, tensor parallel; if both failed, value 0 with the errors."""
+    (object, whether any phase delivered a number).  Headline = ONE tensor-parallel engine over
+    the N GPUs at the global batch of the 1-GPU run (strong scaling).  Only if that phase
+    failed does the data-parallel side result stand in, marked as a fallback; if both failed,
+    value 0 with the errors."""
     B = args.batch
 
     def scaled(m):                               # per-replica numbers -> whole job
@@ -294,36 +313,53 @@ def assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common):
                **_round(r["main"]), "phase_wall_s": r.get("phase_wall_s")}
         if r.get("second"):
             sec["secondary"] = {"model": args.second_model, **_round(r["second"])}
+        if r.get("config"):
+            sec.update(r["config"])
+            sec["global_batch"] = r["config"].get("batch", B)
         return sec
 
-    if phase_ok(dp):
-        m = scaled(dp["main"])
-        value, ms = headline(m)
-        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "weak",
-               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}",
-                          "replica": "tp1, one engine per GPU"},
-               **_round(m), "phase_wall_s": dp.get("phase_wall_s"),
-               "published_reference_check": dp.get("published_reference_check")}
-        if dp.get("second"):
-            out["secondary"] = {"model": args.second_model, **_round(scaled(dp["second"]))}
-        if tp is not None:
-            out["tensor_parallel"] = tp_section(tp)
-        if tpc is not None:
-            out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
-    elif phase_ok(tp):
+    def dp_section(r):
+        if not phase_ok(r):
+            return r
+        sec = {"note": "side result, not the reference's parallelism: N single-GPU replicas, "
+                       "each with its own batch", "parallelism": f"dp{world}", "scaling": "weak",
+               "global_batch": B * world, **_round(scaled(r["main"])),
+               "phase_wall_s": r.get("phase_wall_s")}
+        if r.get("second"):
+            sec["secondary"] = {"model": args.second_model, **_round(scaled(r["second"]))}
+        return sec
+
+    ref_check = (dp or {}).get("published_reference_check") or (tp or {}).get("published_reference_check")
+    if phase_ok(tp):
         value, ms = headline(tp["main"])
         out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "strong",
                "config": {**cfg_common, "global_batch": B, "parallelism": f"tp{world}"},
-               **_round(tp["main"]), "data_parallel_replicas": dp}
+               **_round(tp["main"]), "phase_wall_s": tp.get("phase_wall_s"),
+               "published_reference_check": ref_check}
         if tp.get("second"):
             out["secondary"] = {"model": args.second_model, **_round(tp["second"])}
-        if tpc is not None:
-            out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
+        if dp is not None:
+            out["data_parallel_replicas"] = dp_section(dp)
+    elif phase_ok(dp):
+        m = scaled(dp["main"])
+        value, ms = headline(m)
+        out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "weak",
+               "headline_fallback": "the tensor-parallel phase failed: value is N data-parallel "
+                                    "single-GPU replicas (weak scaling), not the TP metric",
+               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}",
+                          "replica": "tp1, one engine per GPU"},
+               **_round(m), "phase_wall_s": dp.get("phase_wall_s"),
+               "published_reference_check": ref_check, "tensor_parallel": tp}
+        if dp.get("second"):
+            out["secondary"] = {"model": args.second_model, **_round(scaled(dp["second"]))}
     else:
-        out = {"metric": metric, "value": 0.0, **base, "ms_per_step": None, "scaling": "weak",
-               "config": {**cfg_common, "global_batch": B * world, "parallelism": f"dp{world}"},
-               "data_parallel_replicas": dp, "tensor_parallel": tp,
-               "tensor_parallel_p2p_allreduce": tpc}
+        out = {"metric": metric, "value": 0.0, **base, "ms_per_step": None, "scaling": "strong",
+               "config": {**cfg_common, "global_batch": B, "parallelism": f"tp{world}"},
+               "tensor_parallel": tp, "data_parallel_replicas": dp}
+    if tpc is not None:
+        out["tensor_parallel_p2p_allreduce"] = tp_section(tpc)
+    if long_ctx is not None:
+        out["qwen3_32b_tp8_32k_prefill"] = tp_section(long_ctx)
     return out, phase_ok(dp) or phase_ok(tp)
 
 
@@ -346,7 +382,9 @@ def main():
     ap.add_argument("--kv-cache-dtype", choices=["auto", "fp8"], default="auto",
                     help="'fp8' stores K/V as e4m3 (not the headline configuration; reported)")
     ap.add_argument("--port", type=int, default=29533)
-    ap.add_argument("--no-dp", action="store_true", help="with N > 1, skip the data-parallel phase")
+    ap.add_argument("--no-dp", action="store_true", help="with N > 1, skip the data-parallel side phase")
+    ap.add_argument("--long-context", choices=["auto", "on", "off"], default="auto",
+                    help="Qwen3-32B / 32768-token-prompt phase: 'auto' runs it with 8 GPUs")
     ap.add_argument("--no-tp", action="store_true", help="with N > 1, skip the tensor-parallel phase")
     ap.add_argument("--no-p2p", action="store_true",
                     help="with N > 1, skip the TP phase that uses the peer-to-peer all-reduce kernel")
@@ -368,7 +406,7 @@ def main():
     if phase:                                    # child of an orchestrating rank
         res = run_phase(args, phase, rank, local_rank, world)
         if rank == 0:
-            if phase == "dp":
+            if phase in ("dp", "tp"):
                 res["published_reference_check"] = published_reference_check()
             print(json.dumps(res), flush=True)
         return
@@ -397,13 +435,17 @@ def main():
         return
 
     # ---- N > 1: orchestrate one child per phase --------------------------------------
-    dp = None if args.no_dp else spawn_phase(args, "dp", rank, local_rank, world)
+    # headline first: whatever happens to the side phases, its number exists by then
     tp = None if args.no_tp else spawn_phase(args, "tp", rank, local_rank, world)
+    want_long = args.long_context == "on" or (args.long_context == "auto" and world == 8)
+    long_ctx = (spawn_phase(args, "l32k", rank, local_rank, world)
+                if want_long and not args.no_tp else None)
     tpc = (None if args.no_tp or args.no_p2p or world not in (2, 4, 8)
            else spawn_phase(args, "tpc", rank, local_rank, world))
+    dp = None if args.no_dp else spawn_phase(args, "dp", rank, local_rank, world)
     if rank != 0:
         return
-    out, good = assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common)
+    out, good = assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common, long_ctx)
     print(json.dumps(out), flush=True)
     if not good:
         sys.exit(1)

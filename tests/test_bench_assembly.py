@@ -20,32 +20,38 @@ def _res(dec=18000.0, pre=94000.0):
     return {"main": m, "second": dict(m, decode_tok_s=35000.0), "phase_wall_s": 60.0}
 
 
-def _assemble(dp, tp, tpc):
-    out, good = bench.assemble_multi_gpu(ARGS, 8, dp, tp, tpc, "decode tok/s", BASE, CFG)
+def _assemble(dp, tp, tpc, long_ctx=None):
+    out, good = bench.assemble_multi_gpu(ARGS, 8, dp, tp, tpc, "decode tok/s", BASE, CFG, long_ctx)
     json.loads(json.dumps(out))                       # serialisable
     assert REQUIRED <= set(out)
     return out, good
 
 
-def test_data_parallel_headline_scales_per_replica_numbers():
-    out, good = _assemble(_res(), _res(dec=60000.0), {"error": "tpc phase exceeded 600s"})
-    assert good and out["value"] == 8 * 18000.0 and out["scaling"] == "weak"
-    assert out["config"]["parallelism"] == "dp8" and out["config"]["global_batch"] == 2048
-    assert out["prefill_tok_s"] == 8 * 94000.0 and out["secondary"]["decode_tok_s"] == 8 * 35000.0
-    assert out["tensor_parallel"]["decode_tok_s"] == 60000.0
-    assert out["tensor_parallel"]["scaling"] == "strong"
-    assert "error" in out["tensor_parallel_p2p_allreduce"]
-
-
-def test_tensor_parallel_becomes_headline_when_data_parallel_failed():
-    out, good = _assemble({"error": "dp phase child exited with code 1"}, _res(dec=60000.0), None)
+def test_tensor_parallel_is_the_headline_at_the_one_gpu_batch():
+    long_ctx = dict(_res(dec=900.0, pre=120000.0), config={"model": "qwen3-32b", "seq_len": 32768})
+    out, good = _assemble(_res(), _res(dec=60000.0), {"error": "tpc phase exceeded 360s"}, long_ctx)
     assert good and out["value"] == 60000.0 and out["scaling"] == "strong"
-    assert out["config"]["parallelism"] == "tp8" and "error" in out["data_parallel_replicas"]
+    assert out["config"]["parallelism"] == "tp8" and out["config"]["global_batch"] == 256
+    assert out["prefill_tok_s"] == 94000.0 and out["secondary"]["decode_tok_s"] == 35000.0
+    side = out["data_parallel_replicas"]
+    assert side["decode_tok_s"] == 8 * 18000.0 and side["scaling"] == "weak"
+    assert side["global_batch"] == 2048 and "not the reference" in side["note"]
+    assert "error" in out["tensor_parallel_p2p_allreduce"]
+    assert out["qwen3_32b_tp8_32k_prefill"]["seq_len"] == 32768
+    assert out["qwen3_32b_tp8_32k_prefill"]["prefill_tok_s"] == 120000.0
+
+
+def test_data_parallel_stands_in_only_as_a_marked_fallback():
+    out, good = _assemble(_res(), {"error": "tp phase child exited with code 1"}, None)
+    assert good and out["value"] == 8 * 18000.0 and out["scaling"] == "weak"
+    assert out["config"]["parallelism"] == "dp8" and "headline_fallback" in out
+    assert "error" in out["tensor_parallel"]
 
 
 def test_all_phases_failed_still_prints_an_object():
     out, good = _assemble({"error": "a"}, {"error": "b"}, None)
     assert not good and out["value"] == 0.0 and out["tensor_parallel"] == {"error": "b"}
+    assert out["config"]["parallelism"] == "tp8"
     out, good = _assemble(None, None, None)           # --no-dp --no-tp
     assert not good
 
@@ -54,5 +60,5 @@ def test_prefill_only_mode_has_a_headline():
     r = _res()
     for k in ("decode_tok_s", "decode_ms_per_step"):
         r["main"].pop(k)
-    out, good = _assemble(r, None, None)
-    assert good and out["value"] == 8 * 94000.0 and out["ms_per_step"] == 170.0
+    out, good = _assemble(None, r, None)
+    assert good and out["value"] == 94000.0 and out["ms_per_step"] == 170.0
