@@ -194,6 +194,15 @@ class EngineConfig:
     # all-reduce decode-sized tensors with the peer-to-peer kernel (parallel/custom_allreduce.py)
     # instead of RCCL; larger tensors still go to RCCL.  Also switched on by MINIVLLM_CUSTOM_AR=1.
     custom_all_reduce: bool = False
+    # tuning knobs of the multi-GPU path that have no measurement on real xGMI links behind them
+    # yet (None = module default, also settable through the environment, see the modules):
+    # size above which the peer-to-peer all-reduce switches from one-shot to two-shot, how long
+    # one of its kernels waits for a peer, and the chunking of the row-parallel GEMM whose
+    # all-reduce is pipelined against the next chunk's GEMM (parallel/overlap.py)
+    car_one_shot_max_bytes: Optional[int] = None
+    car_timeout_ms: Optional[int] = None
+    overlap_min_chunk_tokens: Optional[int] = None
+    overlap_max_chunks: Optional[int] = None
     # testing aid: with world_size 1 still create a (single-rank) process group and run every
     # tensor-parallel collective through it, graph capture included
     force_tp_group: bool = False

@@ -25,7 +25,9 @@
 // consumer runs a system-scope acquire (invalidate) after its poll matched and before the first
 // load of peer data.  Block b of every rank copies and reads the same element subset, so a
 // block only ever depends on block b of its peers and needs no grid-wide barrier.  Every spin is
-// bounded: on expiry the kernel sets a status word and returns, it never hangs the device.
+// bounded by wall-clock time (the constant 100 MHz counter): on expiry the block sets a sticky
+// status word, does NOT touch the peers' data, overwrites its share of the output with NaN and
+// leaves; the host polls the status word and raises.
 #include "common.h"
 #include <string.h>
 
@@ -36,7 +38,7 @@ namespace {
 constexpr int kMaxRanks = 8;
 constexpr int kMaxBlocks = 64;
 constexpr int kThreads = 512;
-constexpr long kSpinLimit = 1L << 27;          // ~ seconds of polling, then give up
+constexpr long kDefaultTimeoutTicks = 200000000L;      // 2 s of the 100 MHz counter
 
 // One per rank, in peer-visible memory.  counter[phase][block][src rank] is written by rank
 // `src`; epoch[block] is this rank's own call count (one more per launch).
@@ -50,15 +52,26 @@ struct Peers {
     Flags* flags[kMaxRanks];
     uint16_t* stage[kMaxRanks];                // inputs, one buffer per rank
     uint16_t* result[kMaxRanks];               // reduced slices (two-shot)
+    long timeout_ticks;                        // longest wait for a peer, in 10 ns ticks
 };
 
+long g_timeout_ticks = kDefaultTimeoutTicks;
+
+template <int CODE>
+__device__ __forceinline__ u32x4_t nan_vec() {
+    const uint32_t w = CODE == 0 ? 0x7FC07FC0u : 0x7E007E00u;      // quiet NaN, both halves
+    return u32x4_t{w, w, w, w};
+}
+
 // All data stores of the block are done -> tell every peer's block `b`, then wait for theirs.
+// False when a peer did not arrive in time: the caller must not read peer data.
 template <int P>
-__device__ __forceinline__ void block_barrier(const Peers& pr, int rank, int phase, uint32_t epoch,
+__device__ __forceinline__ bool block_barrier(const Peers& pr, int rank, int phase, uint32_t epoch,
                                               bool publish) {
     if (publish) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains
     __syncthreads();
     Flags* mine = pr.flags[rank];
+    int failed = 0;
     if (threadIdx.x < P) {
         if (publish) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope: write back
@@ -66,11 +79,13 @@ __device__ __forceinline__ void block_barrier(const Peers& pr, int rank, int pha
         }
         __hip_atomic_store(&pr.flags[threadIdx.x]->counter[phase][blockIdx.x][rank], epoch,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        long spins = 0;
+        const long t0 = (long)__builtin_amdgcn_s_memrealtime();
+        int spins = 0;
         while (__hip_atomic_load(&mine->counter[phase][blockIdx.x][threadIdx.x], __ATOMIC_RELAXED,
                                  __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-            if (++spins > kSpinLimit) {
+            if ((++spins & 63) == 0 && (long)__builtin_amdgcn_s_memrealtime() - t0 > pr.timeout_ticks) {
                 __hip_atomic_store(&mine->status, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                failed = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(1);
@@ -78,7 +93,7 @@ __device__ __forceinline__ void block_barrier(const Peers& pr, int rank, int pha
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");                 // system scope: invalidate
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();
+    return __syncthreads_or(failed) == 0;
 }
 
 template <int CODE>
@@ -99,10 +114,16 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank
     const long first = (long)blockIdx.x * kThreads + threadIdx.x;
     u32x4_t* xv = reinterpret_cast<u32x4_t*>(x);
 
+    // a peer that never arrived: this block's share of the output becomes NaN (never a sum over
+    // buffers that may not have been written), the call count still advances
+    auto give_up = [&]() {
+        for (long i = first; i < n_vec; i += stride) xv[i] = nan_vec<CODE>();
+        if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+    };
     if (!TWO_SHOT) {
         u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
         for (long i = first; i < n_vec; i += stride) st[i] = xv[i];
-        block_barrier<P>(pr, rank, 0, epoch, true);
+        if (!block_barrier<P>(pr, rank, 0, epoch, true)) { give_up(); return; }
         for (long i = first; i < n_vec; i += stride) {
             u32x4_t v[P];
 #pragma unroll
@@ -120,7 +141,7 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank
         // block b moves the same relative subset of EVERY slice, on every rank
         for (int s = 0; s < P; ++s)
             for (long i = first; i < part; i += stride) st[s * part + i] = xv[s * part + i];
-        block_barrier<P>(pr, rank, 0, epoch, true);
+        if (!block_barrier<P>(pr, rank, 0, epoch, true)) { give_up(); return; }
         u32x4_t* res = reinterpret_cast<u32x4_t*>(pr.result[rank]);
         for (long i = first; i < part; i += stride) {
             u32x4_t v[P];
@@ -134,7 +155,7 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank
             res[rank * part + i] = o;
             xv[rank * part + i] = o;
         }
-        block_barrier<P>(pr, rank, 1, epoch, true);
+        if (!block_barrier<P>(pr, rank, 1, epoch, true)) { give_up(); return; }
         for (long i = first; i < part; i += stride) {
             u32x4_t v[P];
 #pragma unroll
@@ -172,7 +193,16 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
             const int c = threadIdx.x + i * blockDim.x;
             if (c < nchunk) st[(long)row * nchunk + c] = xv[(long)row * nchunk + c];
         }
-    block_barrier<P>(pr, rank, 0, epoch, true);
+    if (!block_barrier<P>(pr, rank, 0, epoch, true)) {
+        for (int row = blockIdx.x; row < rows; row += gridDim.x)
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = threadIdx.x + i * blockDim.x;
+                if (c < nchunk) xv[(long)row * nchunk + c] = nan_vec<CODE>();
+            }
+        if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+        return;
+    }
 
     const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(gamma);
     for (int row = blockIdx.x; row < rows; row += gridDim.x) {
@@ -313,6 +343,7 @@ extern "C" int mvl_car_all_reduce(void* const* flags, void* const* stage, void* 
         pr.stage[p] = (uint16_t*)stage[p];
         pr.result[p] = (uint16_t*)result[p];
     }
+    pr.timeout_ticks = g_timeout_ticks;
     auto st = (hipStream_t)stream;
     return dtype == 0 ? launch_p<0>(pr, world, rank, x, n_vec, two_shot != 0, st)
                       : launch_p<1>(pr, world, rank, x, n_vec, two_shot != 0, st);
@@ -334,10 +365,15 @@ extern "C" int mvl_car_all_reduce_norm(void* const* flags, void* const* stage, i
         pr.stage[p] = (uint16_t*)stage[p];
         pr.result[p] = nullptr;
     }
+    pr.timeout_ticks = g_timeout_ticks;
     auto st = (hipStream_t)stream;
     return dtype == 0 ? launch_norm_p<0>(pr, world, rank, x, residual, gamma, rows, hidden, eps, st)
                       : launch_norm_p<1>(pr, world, rank, x, residual, gamma, rows, hidden, eps, st);
 }
+
+// Longest time a block waits for a peer's flag before it gives up (default 2 s).  Takes effect
+// for launches (and graph captures) made afterwards.
+extern "C" void mvl_car_set_timeout_ms(long ms) { g_timeout_ticks = ms > 0 ? ms * 100000L : kDefaultTimeoutTicks; }
 
 // Reads the sticky status word (0 = every barrier of every call so far completed).
 extern "C" int mvl_car_status(const void* flags_self) {

@@ -15,6 +15,9 @@ ranks are expected to call ``run_worker``.
 from __future__ import annotations
 
 import atexit
+import os
+import sys
+import threading
 import time
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence as Seq, Tuple, Union
@@ -77,6 +80,13 @@ class LLMEngine:
                 p.start()
                 self.workers.append(p)
         self.model_runner = ModelRunner(cfg, 0)
+        if self.workers and self.model_runner.channel is not None:
+            self.model_runner.channel.liveness = self._workers_alive
+        self._step_seq = self._in_step = 0
+        self._watchdog_stop = threading.Event()
+        if self.workers and os.environ.get("MINIVLLM_NO_WATCHDOG") != "1":
+            threading.Thread(target=self._watchdog, name="tp-worker-watchdog",
+                             daemon=True).start()
         self.scheduler = Scheduler(cfg.max_num_sequences, cfg.max_num_batched_tokens,
                                    self.model_runner.num_kv_blocks, cfg.block_size, cfg.eos,
                                    max_model_length=cfg.max_model_length,
@@ -94,20 +104,58 @@ class LLMEngine:
         if self._exited:
             return
         self._exited = True
+        self._watchdog_stop.set()
         atexit.unregister(self.exit)
+        peers_dead = not self._workers_alive()
         try:
-            self.model_runner.call("exit")
+            if peers_dead:
+                # no 'exit' broadcast (nobody would acknowledge it), no closing barrier
+                self.model_runner.exit(peers_dead=True)
+            else:
+                self.model_runner.call("exit")
+        except Exception:
+            peers_dead = True
+            self.model_runner.exit(peers_dead=True)
         finally:
             for p in self.workers:
-                p.join(timeout=30)
+                if not peers_dead:
+                    p.join(timeout=30)
                 if p.is_alive():
-                    p.terminate()
+                    p.terminate()                # this engine's own worker, by handle
+
+    def _workers_alive(self) -> bool:
+        return all(p.is_alive() for p in self.workers)
 
     def _check_workers(self) -> None:
         for p in self.workers:
             if not p.is_alive():
                 raise RuntimeError(f"tensor-parallel worker pid={p.pid} died "
                                    f"(exit code {p.exitcode})")
+
+    WATCHDOG_GRACE_S = 8.0
+
+    def _watchdog(self) -> None:
+        """A worker that dies while rank 0 sits inside a collective leaves rank 0 waiting for
+        the backend's own time-out (minutes), in code no Python exception can reach.  This
+        thread notices the death; if the main thread has not left the engine step on its own
+        within a few seconds (``step`` raises when it gets the chance), the remaining workers
+        are stopped and the process ends with a non-zero code."""
+        while not self._watchdog_stop.wait(0.5):
+            if self._workers_alive():
+                continue
+            dead = [p for p in self.workers if not p.is_alive()]
+            stuck_in = self._in_step                 # 0 = the main thread is not inside a step
+            if self._watchdog_stop.wait(self.WATCHDOG_GRACE_S):
+                return                           # exit() ran: the main thread had its say
+            if stuck_in == 0 or self._in_step != stuck_in:
+                continue                         # it moved on: step() raises on its next call
+            print(f"[engine] tensor-parallel worker pid={dead[0].pid} died (exit code "
+                  f"{dead[0].exitcode}) and the engine is stuck waiting for it: stopping",
+                  file=sys.stderr, flush=True)
+            for p in self.workers:
+                if p.is_alive():
+                    p.terminate()
+            os._exit(70)
 
     # --------------------------------------------------------------- requests
     def add_prompt(self, prompt: Union[str, Seq[int]],
@@ -142,7 +190,12 @@ class LLMEngine:
                              for s in seqs[:len(seqs) - riders]) + riders
         else:
             num_tokens = len(seqs)
-        token_ids = self.model_runner.run(seqs, is_prefill, riders)
+        self._step_seq += 1
+        self._in_step = self._step_seq
+        try:
+            token_ids = self.model_runner.run(seqs, is_prefill, riders)
+        finally:
+            self._in_step = 0
         finished = self.scheduler.postprocess(seqs, token_ids)
         return ([(s.seq_id, s.completion_token_ids) for s in finished], num_tokens, is_prefill)
 

@@ -100,6 +100,8 @@ def default_graph_batch_sizes(max_bs: int) -> List[int]:
 
 
 class ModelRunner:
+    P2P_CHECK_EVERY = 64          # worker ranks look at their all-reduce status this often
+
     def __init__(self, config, rank: int = 0, event=None, spawn_loop: bool = True):
         """``event`` is accepted for signature compatibility with the reference and unused:
         the control channel is addressed by name.  A worker rank (rank > 0) enters
@@ -129,7 +131,11 @@ class ModelRunner:
 
         if (self.on_gpu and cfg.world_size > 1
                 and (cfg.custom_all_reduce or os.environ.get("MINIVLLM_CUSTOM_AR") == "1")):
-            pg.enable_custom_all_reduce(self.device)
+            pg.enable_custom_all_reduce(self.device, one_shot_max_bytes=cfg.car_one_shot_max_bytes,
+                                        timeout_ms=cfg.car_timeout_ms)
+        if cfg.overlap_min_chunk_tokens or cfg.overlap_max_chunks:
+            from minivllm_amd.parallel import overlap
+            overlap.configure(cfg.overlap_min_chunk_tokens, cfg.overlap_max_chunks)
         if self.on_gpu and cfg.tuned_gemms:
             from minivllm_amd.utils.gemm_tuning import enable_tuned_gemms
             enable_tuned_gemms()
@@ -293,12 +299,19 @@ class ModelRunner:
             else:
                 getattr(self, method)(*scalars.get("args", ()))
 
-    def exit(self) -> None:
+    def exit(self, peers_dead: bool = False) -> None:
+        """``peers_dead``: a worker process is gone; tear down locally without anything that
+        would wait for it (no barrier, no collective destroy, no device drain behind a
+        collective that can never complete)."""
         if getattr(self, "_exited", False):
             return
         self._exited = True
-        if self.on_gpu:
+        if self.on_gpu and not peers_dead:
             torch.cuda.synchronize()
+            try:
+                pg.check_custom_all_reduce(synchronize=False)
+            except RuntimeError as e:
+                print(f"[runner] {e}", flush=True)
         # give the device memory back: another engine may be built in this process
         self.graphs.clear()
         self.prefill_graphs.clear()
@@ -314,13 +327,14 @@ class ModelRunner:
         if self.on_gpu:
             torch.cuda.empty_cache()
         if self.channel is not None:
-            try:                    # readers detach before the writer unlinks the segment
-                pg.tp_barrier()
-            except Exception:
-                pass
+            if not peers_dead:
+                try:                # readers detach before the writer unlinks the segment
+                    pg.tp_barrier()
+                except Exception:
+                    pass
             self.channel.close()
             self.channel = None
-        pg.destroy_tensor_parallel()
+        pg.destroy_tensor_parallel(peers_dead)
 
     # ================================================================= timing
     def timer_start(self) -> None:
@@ -652,8 +666,13 @@ class ModelRunner:
         if not warmup and "top_k" in b.arrays:
             tokens = self._resample_filtered(b, tokens, logits)
         if warmup or tokens is None or self.rank != 0:
+            if not warmup and b.step % self.P2P_CHECK_EVERY == 0:
+                pg.check_custom_all_reduce(synchronize=True)     # workers: now and then
             return None
         out = tokens.tolist()
+        # the read-back has drained the stream: looking at the peer-to-peer all-reduce's status
+        # word costs one small copy, so every step of rank 0 can afford it
+        pg.check_custom_all_reduce(synchronize=False)
         self._last_tokens = None if b.is_prefill else out
         return out
 

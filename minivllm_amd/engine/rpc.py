@@ -108,10 +108,13 @@ class ShmBroadcastChannel:
         self._payload = self.shm.buf[self._ctrl_bytes:]
         self._seq = 0
         self.capacity = len(self._payload)
+        # writer side, optional: callable that says whether every reader process is still alive
+        self.liveness = None
 
     # ---------------------------------------------------------------- writer
     def _wait_acks(self, seq: int, timeout_s: float) -> None:
         deadline = time.monotonic() + timeout_s
+        next_alive_check = time.monotonic() + 0.2
         spins = 0
         while True:
             if all(int(self._ctrl[_HDR_WORDS + r]) >= seq for r in range(self.num_readers)):
@@ -119,8 +122,14 @@ class ShmBroadcastChannel:
             spins += 1
             if spins > 200:
                 time.sleep(0.0002)
-            if time.monotonic() > deadline:
+            now = time.monotonic()
+            if now > deadline:
                 raise ChannelTimeout(f"workers did not acknowledge message {seq}")
+            # a reader that died will never acknowledge: do not sit out the whole timeout
+            if self.liveness is not None and now > next_alive_check:
+                next_alive_check = now + 0.2
+                if not self.liveness():
+                    raise ChannelTimeout(f"a worker died before acknowledging message {seq}")
 
     def send(self, method: str, scalars: Dict[str, Any] = None,
              arrays: Dict[str, np.ndarray] = None, timeout_s: float = 300.0) -> None:

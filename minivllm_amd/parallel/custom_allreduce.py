@@ -23,19 +23,33 @@ Opt-in: ``EngineConfig.custom_all_reduce`` / ``MINIVLLM_CUSTOM_AR=1``.
 from __future__ import annotations
 
 import ctypes
+import os
 from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
-ONE_SHOT_MAX_BYTES = 256 << 10          # above this the two-shot form moves fewer bytes per link
+# Above this the two-shot form (which moves fewer bytes per link but has one barrier more) is
+# used.  The crossover has not been measured on a real xGMI node yet: override with
+# MINIVLLM_CAR_ONE_SHOT_MAX_BYTES or EngineConfig.car_one_shot_max_bytes for a first run.
+ONE_SHOT_MAX_BYTES = int(os.environ.get("MINIVLLM_CAR_ONE_SHOT_MAX_BYTES", 256 << 10))
 DEFAULT_MAX_BYTES = 8 << 20             # [1024, 4096] bf16
+# longest wait for a peer inside one kernel before the block gives up (status word set, output
+# poisoned with NaN); MINIVLLM_CAR_TIMEOUT_MS
+DEFAULT_TIMEOUT_MS = int(os.environ.get("MINIVLLM_CAR_TIMEOUT_MS", 2000))
+
+
+class PeerAllReduceError(RuntimeError):
+    """A peer-to-peer all-reduce kernel gave up waiting for a peer: activations of that step
+    (and everything computed from them) are invalid."""
 
 
 class CustomAllReduce:
     def __init__(self, group, rank: int, world_size: int, device: torch.device,
-                 max_bytes: int = DEFAULT_MAX_BYTES):
+                 max_bytes: int = DEFAULT_MAX_BYTES, one_shot_max_bytes: Optional[int] = None,
+                 timeout_ms: Optional[int] = None):
         from minivllm_amd.ops import hip
+        self.one_shot_max_bytes = one_shot_max_bytes or ONE_SHOT_MAX_BYTES
         if world_size not in (2, 4, 8):
             raise ValueError("custom all-reduce supports 2, 4 or 8 ranks")
         self._lib = lib = hip._lib
@@ -54,6 +68,9 @@ class CustomAllReduce:
         lib.mvl_car_all_reduce_norm.argtypes = [ctypes.POINTER(vp)] * 2 + [
             ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
             ctypes.c_int, vp]
+        lib.mvl_car_set_timeout_ms.argtypes = [ctypes.c_long]
+        lib.mvl_car_set_timeout_ms.restype = None
+        lib.mvl_car_set_timeout_ms(int(timeout_ms or DEFAULT_TIMEOUT_MS))
         self._hbytes = lib.mvl_car_ipc_handle_bytes()
         torch.cuda.set_device(device)
         # flags, staging, result: fine-grained (uncached) allocations, coherent across the GPUs
@@ -127,7 +144,7 @@ class CustomAllReduce:
 
     def all_reduce(self, x: torch.Tensor) -> torch.Tensor:
         """In-place sum over the group; every rank ends with bit-identical values."""
-        two_shot = x.numel() * 2 > ONE_SHOT_MAX_BYTES
+        two_shot = x.numel() * 2 > self.one_shot_max_bytes
         rc = self._lib.mvl_car_all_reduce(
             self._flags, self._stage, self._result, self.world, self.rank, x.data_ptr(),
             x.numel(), int(two_shot), 0 if x.dtype == torch.bfloat16 else 1,
@@ -139,7 +156,7 @@ class CustomAllReduce:
     def fits_norm(self, x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor) -> bool:
         """Whether ``all_reduce_add_rms_norm`` takes these operands (one-shot sized, whole
         contiguous rows, 16-byte aligned)."""
-        return (x.dim() == 2 and self.fits(x) and x.numel() * 2 <= ONE_SHOT_MAX_BYTES
+        return (x.dim() == 2 and self.fits(x) and x.numel() * 2 <= self.one_shot_max_bytes
                 and x.shape[1] % 8 == 0 and x.shape[1] <= 32768
                 and residual.shape == x.shape and residual.dtype == x.dtype
                 and residual.is_contiguous() and residual.data_ptr() % 16 == 0
@@ -164,7 +181,7 @@ class CustomAllReduce:
         """All-reduce known integer patterns through both data paths and compare with the exact
         sums (collective call; the result is this rank's own verdict)."""
         P, ok = self.world, True
-        for n in (8 * P * 16, (ONE_SHOT_MAX_BYTES // 2 + 8 * P * 64)):
+        for n in (8 * P * 16, (self.one_shot_max_bytes // 2 + 8 * P * 64)):
             n -= n % (8 * P)
             if n * 2 > self.max_bytes:
                 continue
@@ -188,10 +205,21 @@ class CustomAllReduce:
         ok = ok and bool(torch.equal(h1, h2)) and bool(torch.equal(r1, r2))
         return ok and self.healthy()
 
-    def healthy(self) -> bool:
-        """False once any barrier of any call gave up waiting for a peer (synchronises)."""
-        torch.cuda.synchronize()
+    def healthy(self, synchronize: bool = True) -> bool:
+        """False once any barrier of any call gave up waiting for a peer.  ``synchronize=False``
+        reads the word as of the work that has completed so far (a caller that has just read
+        the step's tokens back is already in sync)."""
+        if synchronize:
+            torch.cuda.synchronize()
         return self._lib.mvl_car_status(self._own[0]) == 0
+
+    def check(self, synchronize: bool = False) -> None:
+        """Raise :class:`PeerAllReduceError` if any call so far timed out on a peer."""
+        if self._own and not self.healthy(synchronize):
+            raise PeerAllReduceError(
+                f"rank {self.rank}: a peer-to-peer all-reduce kernel gave up waiting for a peer "
+                f"(time limit {DEFAULT_TIMEOUT_MS} ms); the outputs of that step were poisoned "
+                f"with NaN.  Restart the engine, or run without custom_all_reduce (RCCL).")
 
     def close(self) -> None:
         """Collective: every rank of the group calls it (peers may still be reading this rank's

@@ -90,7 +90,9 @@ def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
     _HOST_STAGED = on_gpu and dist.get_backend(_TP_GROUP) == "gloo"
 
 
-def enable_custom_all_reduce(device, max_bytes: Optional[int] = None) -> bool:
+def enable_custom_all_reduce(device, max_bytes: Optional[int] = None,
+                             one_shot_max_bytes: Optional[int] = None,
+                             timeout_ms: Optional[int] = None) -> bool:
     """Route all-reduces of tensors that fit through the peer-to-peer kernel.  Collective call:
     every rank of the group must make it.  Returns False (and keeps RCCL) when the group size is
     not 2/4/8 or the set-up fails on ANY rank."""
@@ -101,7 +103,7 @@ def enable_custom_all_reduce(device, max_bytes: Optional[int] = None) -> bool:
     try:
         # the constructor fails on every rank or on none (it exchanges its own status)
         car = CustomAllReduce(_TP_GROUP, _TP_RANK, _TP_SIZE, torch.device(device),
-                              max_bytes or DEFAULT_MAX_BYTES)
+                              max_bytes or DEFAULT_MAX_BYTES, one_shot_max_bytes, timeout_ms)
         verdicts = [None] * _TP_SIZE
         dist.all_gather_object(verdicts, car.self_test(), group=_TP_GROUP)
         if not all(verdicts):                  # wrong sums or a timed-out barrier on some rank
@@ -120,6 +122,12 @@ def custom_all_reduce():
     return _CUSTOM_AR
 
 
+def check_custom_all_reduce(synchronize: bool = False) -> None:
+    """Raise if the peer-to-peer all-reduce ever timed out on a peer (no-op when it is off)."""
+    if _CUSTOM_AR is not None:
+        _CUSTOM_AR.check(synchronize)
+
+
 def set_tp_for_testing(rank: int, world_size: int) -> None:
     """Shard-math tests build layers for an arbitrary (rank, size) without any
     communication backend."""
@@ -127,13 +135,20 @@ def set_tp_for_testing(rank: int, world_size: int) -> None:
     _TP_RANK, _TP_SIZE, _TP_GROUP = rank, world_size, None
 
 
-def destroy_tensor_parallel() -> None:
+def destroy_tensor_parallel(peers_dead: bool = False) -> None:
+    """Leave the TP group.  ``peers_dead``: another rank is known to be gone, so nothing that
+    needs its cooperation is attempted (the peer-to-peer buffers are released without the
+    closing barrier, the process group is left to die with the process)."""
     global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP, _CUSTOM_AR
     if _CUSTOM_AR is not None:
-        _CUSTOM_AR.close()
+        if peers_dead:
+            _CUSTOM_AR._release()
+        else:
+            _CUSTOM_AR.close()
         _CUSTOM_AR = None
     keep = os.environ.get("MINIVLLM_KEEP_PG") == "1"      # another engine will reuse it
-    if _TP_GROUP is not None and _OWNS_DEFAULT_GROUP and dist.is_initialized() and not keep:
+    if (_TP_GROUP is not None and _OWNS_DEFAULT_GROUP and dist.is_initialized() and not keep
+            and not peers_dead):
         dist.destroy_process_group()
     _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP = 0, 1, None, False
     global _HOST_STAGED

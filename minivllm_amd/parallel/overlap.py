@@ -13,6 +13,7 @@ Decode-sized inputs (a few hundred rows) take the plain path: one GEMM, one all-
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -22,16 +23,40 @@ import torch.nn.functional as F
 from . import group as pg
 from .. import ops
 
-# below this many rows per chunk the collective is latency-bound and splitting only hurts
-MIN_CHUNK_TOKENS = 2048
-MAX_CHUNKS = 4
+# Below this many rows per chunk the collective is latency-bound and splitting only hurts.  Both
+# values are estimates until measured on a real xGMI node: MINIVLLM_OVERLAP_MIN_CHUNK_TOKENS /
+# MINIVLLM_OVERLAP_MAX_CHUNKS (or ``configure``) override them for a first run; MAX_CHUNKS = 1
+# switches the pipelining off.
+MIN_CHUNK_TOKENS = int(os.environ.get("MINIVLLM_OVERLAP_MIN_CHUNK_TOKENS", 2048))
+MAX_CHUNKS = int(os.environ.get("MINIVLLM_OVERLAP_MAX_CHUNKS", 4))
 
 
-def plan_chunks(num_tokens: int, min_chunk_tokens: int = MIN_CHUNK_TOKENS,
-                max_chunks: int = MAX_CHUNKS) -> int:
+def configure(min_chunk_tokens: Optional[int] = None, max_chunks: Optional[int] = None) -> None:
+    global MIN_CHUNK_TOKENS, MAX_CHUNKS
+    if min_chunk_tokens:
+        MIN_CHUNK_TOKENS = int(min_chunk_tokens)
+    if max_chunks:
+        MAX_CHUNKS = int(max_chunks)
+
+
+def plan_chunks(num_tokens: int, min_chunk_tokens: Optional[int] = None,
+                max_chunks: Optional[int] = None) -> int:
+    min_chunk_tokens = min_chunk_tokens or MIN_CHUNK_TOKENS
+    max_chunks = max_chunks or MAX_CHUNKS
     if num_tokens < 2 * min_chunk_tokens:
         return 1
     return max(1, min(max_chunks, num_tokens // min_chunk_tokens))
+
+
+def chunk_bounds(num_tokens: int, n: int) -> list:
+    """Row boundaries of ``n`` chunks.  Every chunk but the last has a row count from the
+    prefill token buckets (the sizes the GEMM table is tuned for and the library has seen
+    before); the last takes the rest, which for a bucketed ``num_tokens`` is a multiple of the
+    bucket granularity too."""
+    from ..engine.model_runner import prefill_token_bucket
+    size = prefill_token_bucket(-(-num_tokens // n))
+    bounds = [min(i * size, num_tokens) for i in range(n)] + [num_tokens]
+    return [b for i, b in enumerate(bounds) if i == 0 or b > bounds[i - 1]]
 
 
 def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
@@ -47,12 +72,12 @@ def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
         return pg.tp_all_reduce(ops.linear(x, weight, bias))
     out = torch.empty((T, weight.shape[0]), dtype=x.dtype, device=x.device)
     works = []
-    bounds = [T * i // n for i in range(n + 1)]
+    bounds = chunk_bounds(T, n)
     for lo, hi in zip(bounds[:-1], bounds[1:]):
         y = out[lo:hi]
-        torch.matmul(x[lo:hi], weight.t(), out=y)
-        if bias is not None:
-            y.add_(bias)
+        # same entry point (and so the same tuned-shape lookup) as an unchunked projection
+        torch.addmm(bias, x[lo:hi], weight.t(), out=y) if bias is not None else \
+            torch.mm(x[lo:hi], weight.t(), out=y)
         works.append(dist.all_reduce(y, group=group, async_op=True))
     for w in works:
         w.wait()              # makes the compute stream wait for the collective's event

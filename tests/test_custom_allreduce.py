@@ -126,3 +126,64 @@ def test_ranks_sharing_one_gpu_match_the_sum(world):
         assert err is None, err
         assert worst < 1e-2, (rank, worst)               # one bf16 rounding of the fp32 sum
         assert graph_ok and healthy
+
+
+def _late_peer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    from minivllm_amd.parallel.custom_allreduce import CustomAllReduce, PeerAllReduceError
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank,
+                                world_size=world)
+        car = CustomAllReduce(dist.group.WORLD, rank, world, torch.device("cuda", 0),
+                              max_bytes=1 << 20, timeout_ms=300)
+        x = torch.full((4096,), float(rank + 1), device="cuda", dtype=torch.bfloat16)
+        car.all_reduce(x)                                   # a normal call first
+        ok_first = bool((x.float() == 3.0).all()) and car.healthy()
+        dist.barrier()
+        verdict = None
+        if rank == 0:
+            # the peer never makes this call: the kernel must give up after ~0.3 s, leave NaN
+            # instead of a sum over stale buffers, and the status check must raise
+            y = torch.ones(4096, device="cuda", dtype=torch.bfloat16)
+            h = torch.ones(4, 1024, device="cuda", dtype=torch.bfloat16)
+            r = torch.ones(4, 1024, device="cuda", dtype=torch.bfloat16)
+            gamma = torch.ones(1024, device="cuda", dtype=torch.bfloat16)
+            car.all_reduce(y)
+            car.all_reduce_add_rms_norm(h, r, gamma, 1e-6)
+            torch.cuda.synchronize()
+            raised = False
+            try:
+                car.check()
+            except PeerAllReduceError:
+                raised = True
+            verdict = (bool(torch.isnan(y.float()).all()), bool(torch.isnan(h.float()).all()),
+                       not car.healthy(), raised)
+        dist.barrier()
+        car._release()                                      # no collective close: state is broken
+        dist.destroy_process_group()
+        q.put((rank, ok_first, verdict, None))
+    except Exception:
+        import traceback
+        q.put((rank, False, None, traceback.format_exc()))
+
+
+def test_a_peer_that_never_arrives_poisons_the_output_and_raises():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29750 + os.getpid() % 200
+    procs = [ctx.Process(target=_late_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = {r[0]: r for r in (q.get(timeout=120) for _ in procs)}
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.terminate()
+    for r in res.values():
+        assert r[3] is None, r[3]
+        assert r[1]
+    assert res[0][2] == (True, True, True, True)

@@ -250,3 +250,74 @@ def test_chunked_row_parallel_linear_matches_dense():
         p.join(timeout=30)
     assert all(o[1] for o in out)
     assert out[0][2:] == (1, 4, 2)
+
+
+def test_chunk_bounds_use_bucket_sizes_and_cover_all_rows():
+    from minivllm_amd.engine.model_runner import prefill_token_bucket
+    from minivllm_amd.parallel import overlap
+    for T in (4096, 5120, 16384, 8192 + 512, 4160):
+        for n in (2, 3, 4):
+            b = overlap.chunk_bounds(T, n)
+            assert b[0] == 0 and b[-1] == T and all(x < y for x, y in zip(b, b[1:]))
+            sizes = [y - x for x, y in zip(b, b[1:])]
+            assert len(sizes) <= n
+            assert all(s == prefill_token_bucket(s) for s in sizes[:-1])
+    before = (overlap.MIN_CHUNK_TOKENS, overlap.MAX_CHUNKS)
+    try:
+        overlap.configure(min_chunk_tokens=512, max_chunks=8)
+        assert overlap.plan_chunks(4096) == 8 and overlap.plan_chunks(1000) == 1
+        overlap.configure(max_chunks=1)
+        assert overlap.plan_chunks(1 << 20) == 1
+    finally:
+        overlap.MIN_CHUNK_TOKENS, overlap.MAX_CHUNKS = before
+
+
+_DEAD_WORKER_SCRIPT = r"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, {root!r})
+from minivllm_amd.config import EngineConfig, ModelConfig
+from minivllm_amd.engine.llm_engine import LLMEngine
+from minivllm_amd.sampling_parameters import SamplingParams
+if __name__ == "__main__":
+    model = ModelConfig(vocab_size=331, hidden_size=64, num_heads=4, num_kv_heads=2, head_dim=32,
+                        intermediate_size=96, num_layers=2, max_position=256, base=10000.0)
+    cfg = EngineConfig(model=model, max_num_sequences=4, max_num_batched_tokens=64, block_size=8,
+                       max_model_length=96, eos=-1, device="cpu", dtype=torch.float32, seed=1,
+                       world_size=2, master_port={port}, max_cached_blocks=24)
+    eng = LLMEngine(cfg)
+    eng.add_prompt(list(range(1, 20)), SamplingParams(temperature=0, max_tokens=40, ignore_eos=True))
+    eng.step(); eng.step()
+    eng.workers[0].kill()                       # this engine's own worker, by handle
+    eng.workers[0].join(10)
+    print("KILLED", flush=True)
+    try:
+        eng.step()
+    except RuntimeError as e:
+        print("RAISED", e, flush=True)
+        raise
+"""
+
+
+def test_a_dead_worker_is_reported_and_teardown_does_not_stall():
+    """Killing the TP worker between steps: the next step raises, and interpreter shutdown
+    (atexit -> exit) neither waits for an acknowledgement nor for a barrier with the dead
+    rank."""
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = _DEAD_WORKER_SCRIPT.format(root=root, port=29200 + os.getpid() % 300)
+    t0 = time.monotonic()
+    proc = subprocess.Popen([sys.executable, "-c", script], stdout=subprocess.PIPE,
+                            stderr=subprocess.STDOUT, text=True)
+    try:
+        out, _ = proc.communicate(timeout=150)
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        out, _ = proc.communicate()
+        pytest.fail("engine with a dead worker did not exit:\n" + out[-2000:])
+    assert "KILLED" in out and "RAISED" in out and "died" in out, out[-2000:]
+    assert proc.returncode not in (0, None)
+    # generous bound for a loaded CI machine; the stall this guards against was 15 minutes
+    assert time.monotonic() - t0 < 45, out[-2000:]
