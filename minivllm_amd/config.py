@@ -194,6 +194,11 @@ class EngineConfig:
     # all-reduce decode-sized tensors with the peer-to-peer kernel (parallel/custom_allreduce.py)
     # instead of RCCL; larger tensors still go to RCCL.  Also switched on by MINIVLLM_CUSTOM_AR=1.
     custom_all_reduce: bool = False
+    # steady-state decode: enqueue step n + 1 (inputs derived on the device from step n's
+    # samples) before reading step n's tokens back, so the GPU does not idle while the host
+    # post-processes; single-rank engines only, and on a GPU only with MINIVLLM_PRELAUNCH_GPU=1
+    # (see ModelRunner._can_prelaunch)
+    decode_prelaunch: bool = True
     # tuning knobs of the multi-GPU path that have no measurement on real xGMI links behind them
     # yet (None = module default, also settable through the environment, see the modules):
     # size above which the peer-to-peer all-reduce switches from one-shot to two-shot, how long

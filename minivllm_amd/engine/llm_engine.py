@@ -27,7 +27,7 @@ import torch.multiprocessing as mp
 from minivllm_amd.config import EngineConfig, as_engine_config
 from minivllm_amd.engine.model_runner import ModelRunner
 from minivllm_amd.engine.scheduler import Scheduler
-from minivllm_amd.engine.sequence import Sequence
+from minivllm_amd.engine.sequence import Sequence, SequenceStatus
 from minivllm_amd.parallel.group import env_rank_world
 from minivllm_amd.sampling_parameters import SamplingParams
 from minivllm_amd.utils.tokenizer import load_tokenizer
@@ -176,6 +176,27 @@ class LLMEngine:
         tokens processed, is_prefill).  Tokens processed = newly computed prompt tokens
         for a prefill step, number of sequences for a decode step
         (reference: llm_engine.py:48-60)."""
+        runner = self.model_runner
+        if runner.has_prelaunched():
+            # the previous decode step launched this one ahead: collect it for the sequences
+            # that are still running (one that finished meanwhile just loses its row)
+            ahead = runner.prelaunched_seqs()
+            alive = [i for i, s in enumerate(ahead) if s.status == SequenceStatus.RUNNING]
+            if not alive:
+                runner.drop_prelaunched()
+            else:
+                self._check_workers()
+                seqs = [ahead[i] for i in alive]
+                self.scheduler.consume_plain_decode_step()
+                again = len(alive) == len(ahead) and self.scheduler.next_decode_step_is_plain()
+                self._step_seq += 1
+                self._in_step = self._step_seq
+                try:
+                    token_ids = runner.run_prelaunched(alive, allow_prelaunch=again)
+                finally:
+                    self._in_step = 0
+                finished = self.scheduler.postprocess(seqs, token_ids)
+                return ([(s.seq_id, s.completion_token_ids) for s in finished], len(seqs), False)
         seqs, is_prefill = self.scheduler.schedule()
         if not seqs:
             if not self.scheduler.is_finished():
@@ -193,7 +214,8 @@ class LLMEngine:
         self._step_seq += 1
         self._in_step = self._step_seq
         try:
-            token_ids = self.model_runner.run(seqs, is_prefill, riders)
+            ahead_ok = not is_prefill and self.scheduler.next_decode_step_is_plain()
+            token_ids = self.model_runner.run(seqs, is_prefill, riders, allow_prelaunch=ahead_ok)
         finally:
             self._in_step = 0
         finished = self.scheduler.postprocess(seqs, token_ids)

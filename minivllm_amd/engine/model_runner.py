@@ -70,6 +70,9 @@ class Batch:
                     num_prefill_k_tokens=self.num_prefill_k_tokens)
 
 
+_CHECK_BATCHES = os.environ.get("MINIVLLM_CHECK_BATCHES") == "1"
+
+
 def _pad_block_tables(tables: List[List[int]]) -> np.ndarray:
     """[B, max blocks] int32, rows padded with -1, without a Python-level loop over rows."""
     n = np.fromiter(map(len, tables), np.int64, len(tables))
@@ -161,7 +164,6 @@ class ModelRunner:
         self._decode_prev = None          # (batch list object, arrays) of the last decode step
         self._last_tokens: Optional[List[int]] = None
         self._arange_cache = np.arange(256)
-        self._dec_tables_key = None       # (padded batch, num_seqs) the host table image holds
         self.graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
         self.graph_pool = None
         self.kv_cache: Optional[torch.Tensor] = None
@@ -236,7 +238,20 @@ class ModelRunner:
         #          + misc + block tables
         self._pre_words = 0          # grown on demand
         pin = self.on_gpu
-        self._dec_host = torch.zeros(self._dec_words, dtype=torch.int32, pin_memory=pin)
+        # two pinned staging blocks, used alternately: with a decode step launched ahead of the
+        # previous one's read-back (see ``run``), the host fills the block of step n + 1 while
+        # the upload of step n may still be pending
+        self._dec_hosts = [torch.zeros(self._dec_words, dtype=torch.int32, pin_memory=pin)
+                           for _ in range(2)]
+        self._dec_host = self._dec_hosts[0]
+        self._dec_flip = 0
+        # per block: (padded batch, num_seqs, version of the block tables) of its table image
+        self._dec_tables_keys = [None, None]
+        self._tables_version = 0
+        self._tok_hosts = [torch.zeros(max(mb, 1), dtype=torch.int32, pin_memory=pin)
+                           for _ in range(2)]
+        self._tok_flip = 0
+        self._spec = None                        # decode step launched ahead, not yet collected
         self._dec_dev = torch.zeros(self._dec_words, dtype=torch.int32, device=self.device)
         self._pre_host = None
         self._pre_dev = None
@@ -306,6 +321,7 @@ class ModelRunner:
         if getattr(self, "_exited", False):
             return
         self._exited = True
+        self._spec = None
         if self.on_gpu and not peers_dead:
             torch.cuda.synchronize()
             try:
@@ -537,9 +553,15 @@ class ModelRunner:
         return torch.tensor([s.temperature for s in seqs], dtype=torch.float32, device=self.device)
 
     # ================================================================== run
-    def run(self, seqs: Seq[Sequence], is_prefill: bool, num_decode: int = 0) -> Optional[List[int]]:
+    def run(self, seqs: Seq[Sequence], is_prefill: bool, num_decode: int = 0,
+            allow_prelaunch: bool = False) -> Optional[List[int]]:
         """Rank 0 entry point for one step; returns the sampled token per sequence.
-        ``num_decode`` > 0 (prefill steps only): the last that many sequences decode."""
+        ``num_decode`` > 0 (prefill steps only): the last that many sequences decode.
+        ``allow_prelaunch`` (decode steps): the caller guarantees that the NEXT step is a plain
+        decode step of the same sequences (nobody crosses a KV-block edge, nothing waits to be
+        admitted), so that step may be launched before this one's tokens are read back; the
+        caller then collects it with ``run_prelaunched``."""
+        assert self._spec is None, "a step launched ahead must be collected first"
         if is_prefill:
             self._decode_prev = None
             batch = self.prepare_prefill(seqs, num_decode)
@@ -550,7 +572,135 @@ class ModelRunner:
         if self.world_size > 1 and self.rank == 0:
             self.channel.send("run_batch", batch.scalars(), batch.arrays)
         with torch.inference_mode(), trace_range("prefill_step" if is_prefill else "decode_step"):
+            if allow_prelaunch and self._can_prelaunch(batch):
+                tokens_dev = self._launch_decode(batch)
+                pending = self._read_tokens_async(tokens_dev, batch.num_seqs)
+                self._prelaunch_after(seqs, batch, tokens_dev)
+                out = self._finish_read(pending)
+                self._last_tokens = out
+                return out
             return self.execute(batch)
+
+    # ---------------------------------------------------- decode launched one step ahead
+    # The GPU otherwise idles between two decode steps while the host reads the tokens back,
+    # updates the sequences, schedules and fills the next step's inputs (~0.2-0.4 ms, 6 % of a
+    # Qwen3-0.6B step at batch 256).  In steady-state decode none of that is needed to START
+    # the next step: its positions / slots / lengths follow from this step's, and its input
+    # tokens are this step's samples, which are already on the device.  So step n + 1 is
+    # enqueued right behind step n (device-to-device copy of the samples into the input
+    # buffer, upload of the other inputs from the second staging block, graph replay), and
+    # only then does the host wait for step n's tokens.  A sequence that turns out to have
+    # finished at step n (EOS) simply has its row of step n + 1 ignored: what that row wrote
+    # to the KV cache lies beyond the sequence's tokens, in a block that is not shared.
+    def _can_prelaunch(self, b: Batch) -> bool:
+        if (b.is_prefill or not self.cfg.decode_prelaunch or self.world_size > 1
+                or pg.collectives_active() or "top_k" in b.arrays):
+            return False
+        if os.environ.get("MINIVLLM_NO_PRELAUNCH") == "1":
+            return False
+        if self.on_gpu:
+            # Not enabled on the GPU by default: the first run of the GPU test suite with this
+            # path active ended in a device memory fault whose cause has not been found (the
+            # same control flow, replayed on the CPU with every staging block validated, is
+            # clean: tests/test_decode_launch_ahead.py).  MINIVLLM_PRELAUNCH_GPU=1 opts in.
+            if os.environ.get("MINIVLLM_PRELAUNCH_GPU") != "1":
+                return False
+            if self._graph_bucket(b.num_seqs) is None:
+                return False             # eager GPU steps are host-bound anyway
+        # the step after this one reads position = context length: inside the model's tables?
+        return int(b.arrays["context_lens"].max()) + 1 < self.cfg.max_model_length
+
+    def _launch_decode(self, b: Batch, input_ids_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Enqueue one decode step; returns the device tensor its sampled tokens land in.
+        ``input_ids_dev``: take the input tokens from this device tensor (the previous step's
+        samples) instead of the host arrays."""
+        B = b.num_seqs
+        bucket = self._graph_bucket(B)
+        padded = bucket if bucket is not None else B
+        self._fill_decode_host(b, padded)
+        if _CHECK_BATCHES:
+            self._check_decode_image(b, padded)
+        self._dec_dev.copy_(self._dec_host, non_blocking=True)
+        if input_ids_dev is not None:
+            self._dec_view(self._dec_dev, "input_ids", B).copy_(input_ids_dev)
+        if bucket is not None:
+            self.graphs[bucket].replay()
+            return self._graph_out[bucket][:B]
+        t = self._decode_tensors(B)
+        set_context(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
+                    block_tables=t["block_tables"], positions=t["positions"],
+                    max_context_len=b.max_context_len, num_seqs=B)
+        tokens = self._forward_and_sample(t)
+        reset_context()
+        return tokens
+
+    def _read_tokens_async(self, tokens_dev: torch.Tensor, n: int):
+        """Start copying ``n`` sampled tokens to the host; returns what ``_finish_read`` needs."""
+        if not self.on_gpu:
+            return tokens_dev[:n].clone(), None
+        self._tok_flip ^= 1
+        host = self._tok_hosts[self._tok_flip][:n]
+        host.copy_(tokens_dev[:n], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return host, ev
+
+    def _finish_read(self, pending) -> List[int]:
+        host, ev = pending
+        if ev is not None:
+            ev.synchronize()
+            pg.check_custom_all_reduce(synchronize=False)
+        return host.tolist()
+
+    def _prelaunch_after(self, seqs, b: Batch, tokens_dev: torch.Tensor) -> None:
+        """Enqueue the decode step that follows ``b`` for the same sequences."""
+        a, bs = b.arrays, self.block_size
+        B = b.num_seqs
+        lens = a["context_lens"] + 1
+        pos = lens - 1
+        tables = a["block_tables"]
+        blk = tables[self._arange(B), pos // bs]
+        arrays = dict(input_ids=np.zeros(B, np.int32),         # replaced on the device
+                      positions=pos, slot_mapping=blk * bs + pos % bs, context_lens=lens,
+                      temperatures=a["temperatures"], block_tables=tables)
+        m = int(lens.max())
+        nxt = Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1, max_seqlen_k=m,
+                    max_context_len=m, arrays=arrays, tables_unchanged=True)
+        self.step_counter += 1
+        nxt.step = self.step_counter
+        out_dev = self._launch_decode(nxt, input_ids_dev=tokens_dev)
+        self._spec = dict(seqs=seqs, batch=nxt, tokens=out_dev)
+
+    def has_prelaunched(self) -> bool:
+        return self._spec is not None
+
+    def prelaunched_seqs(self):
+        return self._spec["seqs"]
+
+    def drop_prelaunched(self) -> None:
+        """Forget the step launched ahead (every sequence of it has left)."""
+        if self._spec is not None and self.on_gpu:
+            torch.cuda.synchronize()
+        self._spec = None
+        self._decode_prev = None
+        self._last_tokens = None
+
+    def run_prelaunched(self, alive: Seq[int], allow_prelaunch: bool = False) -> List[int]:
+        """Collect the step launched ahead: the tokens of the rows ``alive`` (indices into
+        ``prelaunched_seqs()``; the other sequences finished in the meantime).  With every
+        row alive and ``allow_prelaunch`` the step after it is launched ahead in turn."""
+        spec, self._spec = self._spec, None
+        b, seqs = spec["batch"], spec["seqs"]
+        with torch.inference_mode(), trace_range("decode_step"):
+            pending = self._read_tokens_async(spec["tokens"], b.num_seqs)
+            if allow_prelaunch and len(alive) == b.num_seqs and self._can_prelaunch(b):
+                self._prelaunch_after(seqs, b, spec["tokens"])
+            out = self._finish_read(pending)
+        # a normal step for the same list continues from here (prepare_decode's shortcut)
+        b.arrays["input_ids"] = np.asarray(out, dtype=np.int32)
+        self._decode_prev = (seqs, b.arrays)
+        self._last_tokens = out
+        return [out[i] for i in alive]
 
     # ------------------------------------------------------------- uploads
     def _upload_prefill(self, b: Batch):
@@ -589,6 +739,8 @@ class ModelRunner:
         a = b.arrays
         B = b.num_seqs
         MBmax = self.max_blocks_per_seq
+        self._dec_flip ^= 1
+        self._dec_host = self._dec_hosts[self._dec_flip]
         host = self._dec_host.numpy()
 
         def put(name, values, fill):
@@ -602,10 +754,12 @@ class ModelRunner:
         put("context_lens", a["context_lens"], 0)
         put("temperatures", a["temperatures"].astype(np.float32).view(np.int32), 0)
         host[self._dec_off["misc"][0]] = b.step
-        key = (padded_bs, B)
-        if b.tables_unchanged and self._dec_tables_key == key:
-            return                        # the table image already holds these rows
-        self._dec_tables_key = key
+        if not b.tables_unchanged:
+            self._tables_version += 1     # a new set of block tables (every rank counts alike)
+        key = (padded_bs, B, self._tables_version)
+        if self._dec_tables_keys[self._dec_flip] == key:
+            return                        # this block's table image already holds these rows
+        self._dec_tables_keys[self._dec_flip] = key
         off, _ = self._dec_off["block_tables"]
         tab = host[off:off + padded_bs * MBmax].reshape(padded_bs, MBmax)
         mb = a["block_tables"].shape[1]
@@ -615,6 +769,29 @@ class ModelRunner:
         tab[:B, mb:] = -1
         if padded_bs > B:
             tab[B:] = -1
+
+    def _check_decode_image(self, b: Batch, padded_bs: int) -> None:
+        """Debug aid (MINIVLLM_CHECK_BATCHES=1): the staging block about to be uploaded must
+        describe exactly this batch - every row's slot inside a block its table names, no
+        unset table entry below a row's context length, padding rows inert.  A kernel handed
+        anything else reads or writes outside the KV cache."""
+        host = self._dec_host.numpy()
+        B, bs, MB = b.num_seqs, self.block_size, self.max_blocks_per_seq
+        get = lambda name, n: host[self._dec_off[name][0]:self._dec_off[name][0] + n]
+        lens, pos, slots = get("context_lens", padded_bs), get("positions", padded_bs), get("slot_mapping", padded_bs)
+        tab = get("block_tables", padded_bs * MB).reshape(padded_bs, MB)
+        a = b.arrays
+        assert (lens[:B] == a["context_lens"]).all() and (pos[:B] == a["positions"]).all()
+        assert (slots[:B] == a["slot_mapping"]).all()
+        mb = a["block_tables"].shape[1]
+        assert (tab[:B, :mb] == a["block_tables"]).all(), "stale block-table image"
+        assert (tab[:B, mb:] == -1).all()
+        for i in range(B):
+            need = (int(lens[i]) + bs - 1) // bs
+            assert (tab[i, :need] >= 0).all() and (tab[i, :need] < self.num_kv_blocks).all(), (i, tab[i], lens[i])
+            assert slots[i] == tab[i, pos[i] // bs] * bs + pos[i] % bs and pos[i] == lens[i] - 1
+            assert 0 <= pos[i] < self.cfg.max_model_length
+        assert (lens[B:] == 0).all() and (slots[B:] == -1).all() and (tab[B:] == -1).all()
 
     def _decode_tensors(self, n: int):
         d = self._dec_dev
@@ -650,6 +827,8 @@ class ModelRunner:
             bucket = self._graph_bucket(B)
             padded = bucket if bucket is not None else B
             self._fill_decode_host(b, padded)
+            if _CHECK_BATCHES:
+                self._check_decode_image(b, padded)
             self._dec_dev.copy_(self._dec_host, non_blocking=True)
             if bucket is not None:
                 self.graphs[bucket].replay()

@@ -204,6 +204,20 @@ class Scheduler:
             self._decode_batch = None
         return scheduled, False
 
+    # ------------------------------------------------ decode steps launched ahead
+    def next_decode_step_is_plain(self) -> bool:
+        """After a decode step has been scheduled: will the step after it be the same batch
+        again with nothing to allocate, publish or admit (so that the runner may launch it
+        before this one's tokens are known)?"""
+        return (self._decode_batch is not None and self._plain_decode_steps > 0
+                and not self.waiting and not self.prefilling)
+
+    def consume_plain_decode_step(self) -> None:
+        """Account for a step that ran without ``schedule()`` having been asked (it had been
+        launched ahead): one plain step of the current batch is used up."""
+        if self._decode_batch is not None and self._plain_decode_steps > 0:
+            self._plain_decode_steps -= 1
+
     def _add_decode_riders(self, scheduled: List[Sequence], num_tokens: int) -> None:
         """Append every running sequence that can take its next token without evicting anyone
         (a sequence that needs a KV block the pool cannot give simply sits this step out)."""

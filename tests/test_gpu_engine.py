@@ -1,5 +1,7 @@
 """End-to-end engine checks on a real MI355X: HIP path vs the CPU fp32 oracle, hipGraph replay
 vs eager, prefix-cache reuse, preemption."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -424,3 +426,44 @@ def test_fp8_kv_cache_with_tp2_on_one_gpu(gpu):
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
     assert same / total > 0.9, (same, total)
+
+
+def test_decode_steps_launched_ahead_do_not_change_outputs(gpu):
+    """Steady-state decode enqueues step n + 1 before step n's tokens are read back.  With
+    requests of different lengths (rows drop out one by one), a stop token (a finish the host
+    cannot foresee) and an abort in mid-flight, greedy outputs must equal the plain loop's."""
+    if os.environ.get("MINIVLLM_PRELAUNCH_GPU") != "1":
+        pytest.skip("launch-ahead decode is opt-in on the GPU (MINIVLLM_PRELAUNCH_GPU=1): its "
+                    "first GPU run ended in a device memory fault that is not understood yet")
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    prompts = _prompts(8, lo=20, hi=120, seed=9)
+    lens = [5, 40, 17, 33, 40, 9, 28, 40]
+
+    def run(ahead, stop=()):
+        eng = LLMEngine(_cfg(enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8], decode_prelaunch=ahead))
+        seqs = [eng.add_prompt(p, SamplingParams(temperature=0, max_tokens=n, ignore_eos=True,
+                                                 stop_token_ids=list(stop)))
+                for p, n in zip(prompts, lens)]
+        done, steps, launched = {}, 0, 0
+        while not eng.is_finished():
+            finished, _, _ = eng.step()
+            done.update(finished)
+            launched += eng.model_runner.has_prelaunched()
+            steps += 1
+            if steps == 12:
+                assert eng.scheduler.abort(seqs[4])
+        out = [done.get(s.seq_id) for s in seqs]
+        bm = eng.scheduler.block_manager
+        assert bm.num_free_blocks == bm.num_blocks
+        eng.exit()
+        return out, launched
+
+    plain, n0 = run(False)
+    ahead, n1 = run(True)
+    assert n0 == 0 and n1 > 10, (n0, n1)
+    assert ahead == plain
+    # a token that some sequence produces half-way becomes a stop token
+    stop = [plain[1][20], plain[7][11]]
+    plain_s, _ = run(False, stop)
+    ahead_s, _ = run(True, stop)
+    assert ahead_s == plain_s and len(plain_s[1]) <= 21 and len(plain_s[7]) <= 12
