@@ -46,7 +46,16 @@ struct PrefillArgs {
     float scale_log2;
     int B, Hq, Hkv, n_qtiles;
     int total_wg;
+#ifdef MVL_PREFILL_PROBE
+    unsigned long long* probe;                 // [total_wg][8] timestamps (tools/native/prefill_phase_probe.hip)
+#endif
 };
+
+#ifdef MVL_PREFILL_PROBE
+#define MVL_PROBE(slot, value) do { if (threadIdx.x == 0) a.probe[(long)blockIdx.x * 8 + (slot)] = (value); } while (0)
+#else
+#define MVL_PROBE(slot, value) do { } while (0)
+#endif
 
 template <int CODE, int D, bool PAGED>
 __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs a) {
@@ -60,6 +69,7 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 
     // two buffers of {K tile, V tile}; tile t lives in buffer t & 1
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    MVL_PROBE(0, wall_clock64());
 
     // ---- work decomposition: XCD-aware remap of the linear block id -----------------
     int id = blockIdx.x;
@@ -163,6 +173,10 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
         if (n_tiles > 1) load_block_ids(1, ids_next);
     }
     __syncthreads();                         // drains the LDS-DMA (vmcnt) and meets the waves
+    MVL_PROBE(1, wall_clock64());
+    MVL_PROBE(4, (unsigned long long)n_tiles);
+    MVL_PROBE(5, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4));    // HW_ID
+    MVL_PROBE(6, (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20));   // XCC_ID
 
     // transposed-read lane constants: 16-lane group gq = lane >> 4; (gq & 1) picks the
     // 16-column half of a 32-wide d block, hh = gq >> 1 picks the key rows
@@ -267,7 +281,9 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     };
     const int t_split = min(n_tiles, (q0 + pos_off + 1) / kBN);   // uniform for the workgroup
     run_tiles(std::false_type{}, 0, t_split);
+    MVL_PROBE(2, wall_clock64());
     run_tiles(std::true_type{}, t_split, n_tiles);
+    MVL_PROBE(3, wall_clock64());
 
     // ---- epilogue: O[q][d] = O^T / l --------------------------------------------------
     l_run += __shfl_xor(l_run, 32, 64);

@@ -333,6 +333,76 @@ __global__ __launch_bounds__(256) void mid_reduce_kernel(const float* __restrict
     *reinterpret_cast<u32x2_t*>(out + (long)row * o_stride + col) = o;
 }
 
+// Consumer of the K-slice partials when the projection feeds (residual add +) RMSNorm:
+// r = sum_s ws[s][row] (+ bias) + residual[row], rounded to the storage dtype and written back
+// to `residual`; out[row] = r * rsqrt(mean(r^2) + eps) * weight.  One workgroup per row, 8
+// columns per thread and pass; the row stays in registers between the two phases.  Replaces
+// the partial-sum kernel above and the add + norm kernel that would follow it.
+template <int CODE, int MAXC>
+__global__ void splitk_add_rms_norm_kernel(const float* __restrict__ ws,
+                                           const uint16_t* __restrict__ bias,
+                                           uint16_t* residual,
+                                           const uint16_t* __restrict__ weight,
+                                           uint16_t* __restrict__ out, int M, int N, int S,
+                                           long r_stride, long o_stride, float eps) {
+    __shared__ float scratch[16];
+    const int row = blockIdx.x;
+    const int nchunk = N >> 3;
+    const long slab = (long)M * N;
+    const float* p = ws + (long)row * N;
+    u32x4_t* rr = reinterpret_cast<u32x4_t*>(residual + (long)row * r_stride);
+    const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(weight);
+    u32x4_t wv[MAXC];
+    float v[MAXC][8];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * blockDim.x;
+        if (c < nchunk) {
+            wv[i] = wr[c];
+            const u32x4_t rv = rr[c];
+            f32x4_t lo = *reinterpret_cast<const f32x4_t*>(p + c * 8);
+            f32x4_t hi = *reinterpret_cast<const f32x4_t*>(p + c * 8 + 4);
+#pragma unroll 4
+            for (int s = 1; s < S; ++s) {
+                lo += *reinterpret_cast<const f32x4_t*>(p + s * slab + c * 8);
+                hi += *reinterpret_cast<const f32x4_t*>(p + s * slab + c * 8 + 4);
+            }
+            float r[8];
+            unpack8<CODE>(rv, r);
+            if (bias != nullptr) {
+                float b[8];
+                unpack8<CODE>(reinterpret_cast<const u32x4_t*>(bias)[c], b);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) r[j] += b[j];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float t = (j < 4 ? lo[j] : hi[j - 4]) + r[j];
+                v[i][j] = DType<CODE>::to_float(DType<CODE>::from_float(t));
+                ss += v[i][j] * v[i][j];
+            }
+            rr[c] = pack8<CODE>(v[i]);
+        } else {
+            wv[i] = u32x4_t{0, 0, 0, 0};
+        }
+    }
+    ss = block_sum(ss, scratch);
+    const float rstd = rsqrtf(ss / (float)N + eps);
+    u32x4_t* orow = reinterpret_cast<u32x4_t*>(out + (long)row * o_stride);
+#pragma unroll
+    for (int i = 0; i < MAXC; ++i) {
+        const int c = threadIdx.x + i * blockDim.x;
+        if (c < nchunk) {
+            float w[8], o[8];
+            unpack8<CODE>(wv[i], w);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rstd * w[j];
+            orow[c] = pack8<CODE>(o);
+        }
+    }
+}
+
 template <int CODE, int BM, int BN, int WM, int D, bool SWI, bool NT>
 int launch_tile(MidArgs a, int splits, hipStream_t st) {
     const int tiles = a.N / BN;
@@ -389,6 +459,7 @@ extern "C" int mvl_mid_gemm(const void* x, long x_stride, const void* w, const v
     a.ksteps = K / kBK;
     a.ksteps_per_split = (a.ksteps + splits - 1) / splits;
     splits = (a.ksteps + a.ksteps_per_split - 1) / a.ksteps_per_split;     // no empty slices
+    if (out == nullptr && (splits == 1 || swiglu)) return -1;              // partials only: needs a K split
     auto st = (hipStream_t)stream;
     int rc;
 #define MVL_DISPATCH(CODE)                                                                     \
@@ -398,7 +469,7 @@ extern "C" int mvl_mid_gemm(const void* x, long x_stride, const void* w, const v
                       : launch_shape<CODE, false, false>(a, bm, bn, splits, st))
     if (dtype == 0) { MVL_DISPATCH(0); } else { MVL_DISPATCH(1); }
 #undef MVL_DISPATCH
-    if (rc != 0 || splits == 1) return rc;
+    if (rc != 0 || splits == 1 || out == nullptr) return rc;      // out == nullptr: partials only
     const int n_out = swiglu ? N / 2 : N;
     const long threads = (long)M * (n_out / 4);
     const int blocks = (int)((threads + 255) / 256);
@@ -410,5 +481,53 @@ extern "C" int mvl_mid_gemm(const void* x, long x_stride, const void* w, const v
         if (swiglu) mid_reduce_kernel<1, true><<<blocks, 256, 0, st>>>(a.ws, B, O, o_stride, M, N, splits, n_out);
         else mid_reduce_kernel<1, false><<<blocks, 256, 0, st>>>(a.ws, B, O, o_stride, M, N, splits, n_out);
     }
+    return MVL_CHECK_LAUNCH();
+}
+
+// Number of K slices mvl_mid_gemm really writes for a requested `splits` (no empty slices).
+extern "C" int mvl_mid_effective_splits(int K, int splits) {
+    if (K <= 0 || K % kBK != 0 || splits < 1) return -1;
+    const int ksteps = K / kBK, per = (ksteps + splits - 1) / splits;
+    return (ksteps + per - 1) / per;
+}
+
+// ws [S][M][N] fp32 (K-slice partials from mvl_mid_gemm with out == nullptr) -> out [M, N]
+extern "C" int mvl_mid_reduce(const void* ws, const void* bias, void* out, long o_stride, int M,
+                              int N, int S, int dtype, void* stream) {
+    if (M == 0) return 0;
+    if (N % 4 != 0 || S < 1 || (dtype != 0 && dtype != 1)) return -1;
+    const long threads = (long)M * (N / 4);
+    const int blocks = (int)((threads + 255) / 256);
+    auto st = (hipStream_t)stream;
+    auto W = (const float*)ws; auto B = (const uint16_t*)bias; auto O = (uint16_t*)out;
+    if (dtype == 0) mid_reduce_kernel<0, false><<<blocks, 256, 0, st>>>(W, B, O, o_stride, M, N, S, N);
+    else mid_reduce_kernel<1, false><<<blocks, 256, 0, st>>>(W, B, O, o_stride, M, N, S, N);
+    return MVL_CHECK_LAUNCH();
+}
+
+// residual <- sum_s ws[s] (+ bias) + residual; out = rms_norm(residual) * weight.  N % 8 == 0,
+// N <= 32768; residual and out rows 16-byte aligned.
+extern "C" int mvl_splitk_add_rms_norm(const void* ws, const void* bias, void* residual,
+                                       const void* weight, void* out, int M, int N, int S,
+                                       long r_stride, long o_stride, float eps, int dtype,
+                                       void* stream) {
+    if (M == 0) return 0;
+    if (N % 8 != 0 || N > 8 * 1024 * 4 || S < 1 || (dtype != 0 && dtype != 1)
+        || r_stride % 8 != 0 || o_stride % 8 != 0) return -1;
+    const int nchunk = N / 8;
+    int threads = 64;
+    while (threads < nchunk && threads < 1024) threads <<= 1;
+    const int per = (nchunk + threads - 1) / threads;
+    auto st = (hipStream_t)stream;
+    auto W = (const float*)ws; auto B = (const uint16_t*)bias; auto R = (uint16_t*)residual;
+    auto G = (const uint16_t*)weight; auto O = (uint16_t*)out;
+#define MVL_SK(CODE, MAXC) \
+    splitk_add_rms_norm_kernel<CODE, MAXC><<<M, threads, 0, st>>>(W, B, R, G, O, M, N, S, r_stride, o_stride, eps)
+    if (dtype == 0) {
+        if (per <= 1) MVL_SK(0, 1); else if (per <= 2) MVL_SK(0, 2); else MVL_SK(0, 4);
+    } else {
+        if (per <= 1) MVL_SK(1, 1); else if (per <= 2) MVL_SK(1, 2); else MVL_SK(1, 4);
+    }
+#undef MVL_SK
     return MVL_CHECK_LAUNCH();
 }

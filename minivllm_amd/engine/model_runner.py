@@ -212,7 +212,11 @@ class ModelRunner:
         for name, (ws, swiglu) in roles.items():
             self.decode_gemm_choices[name] = hip.tune_skinny_gemm(ws, swiglu)
             if self.max_bs > hip.SKINNY_MAX_ROWS:
-                self.mid_gemm_choices[name] = hip.tune_mid_gemm(ws, swiglu, rows=rows)
+                # o / down feed a residual add + norm: on one rank their K-slice sum is folded
+                # into that norm, so they are tuned together with it
+                to_norm = name in ("o", "down") and self.world_size == 1
+                self.mid_gemm_choices[name] = hip.tune_mid_gemm(ws, swiglu, rows=rows,
+                                                                to_norm=to_norm)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         if self.rank == 0 and self.cfg.log_stats:

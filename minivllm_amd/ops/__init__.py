@@ -21,10 +21,18 @@ def _on_gpu(t: torch.Tensor) -> bool:
 
 
 def rms_norm(x, weight, eps):
+    if _is_partials(x):
+        x = x.materialize()
     return _hip().rms_norm(x, weight, eps) if _on_gpu(x) else torch_ref.rms_norm(x, weight, eps)
 
 
+def _is_partials(x) -> bool:
+    return not torch.is_tensor(x) and type(x).__name__ == "SplitKPartials"
+
+
 def add_rms_norm(x, residual, weight, eps):
+    if _is_partials(x):
+        return x.add_rms_norm(residual, weight, eps)
     if _on_gpu(x):
         return _hip().add_rms_norm(x, residual, weight, eps)
     return torch_ref.add_rms_norm(x, residual, weight, eps)
@@ -81,19 +89,22 @@ def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scal
                                                        context_lens, scale))
 
 
-def linear(x, weight, bias=None):
+def linear(x, weight, bias=None, to_norm=False):
     """``x @ weight.T (+ bias)``: the library GEMM, except for decode-sized GPU inputs (<= 16
     rows: skinny kernel; 17..256 rows: mid-batch kernel) of the shapes where the hand-written
-    weight-streaming kernels were measured to be faster on this machine."""
+    weight-streaming kernels were measured to be faster on this machine.  ``to_norm``: the
+    caller passes the result straight to ``norm_linear`` / ``add_rms_norm`` (and to nothing
+    else), which lets a K-split mid-batch GEMM hand over its unsummed slices
+    (``hip.SplitKPartials``) for the norm kernel to sum."""
     if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 256:
         h = _hip()
         if x.shape[0] <= 16:
             if h.skinny_gemm_pays(x, weight):
                 return h.skinny_linear(x, weight, bias)
         else:
-            c = h.mid_gemm_choice(x, weight)
+            c = h.mid_gemm_choice(x, weight, to_norm=to_norm)
             if c is not None:
-                return h.mid_linear(x, weight, bias, False, c[0], c[1], c[2])
+                return h.mid_linear(x, weight, bias, False, c[0], c[1], c[2], defer=to_norm)
     return F.linear(x, weight, bias)
 
 
@@ -128,6 +139,9 @@ def norm_linear(x, residual, gamma, eps, weight, bias=None, swiglu=False, gamma_
     if getattr(x, "_mvl_pending_reduce", False):       # row-parallel partial sum: reduce here
         from ..parallel import group as pg
         h, residual = pg.tp_reduce_add_rms_norm(x, residual, gamma, eps)
+        return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), residual
+    if _is_partials(x):                                # K-split GEMM slices: summed by the norm
+        h, residual = x.add_rms_norm(residual, gamma, eps)
         return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), residual
     if gamma_folded and fuses_norm_linear(x, weight, swiglu):
         return _hip().skinny_norm_linear(x, residual, eps, weight, bias, swiglu)

@@ -72,6 +72,14 @@ _skinny_norm = _sig("mvl_skinny_norm_gemm", _c_void, _c_long, _c_void, _c_long, 
 _mid = _sig("mvl_mid_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_void, _c_int,
             _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void)
 
+_mid_eff_splits = _lib.mvl_mid_effective_splits
+_mid_eff_splits.argtypes = [_c_int, _c_int]
+_mid_eff_splits.restype = _c_int
+_mid_reduce = _sig("mvl_mid_reduce", _c_void, _c_void, _c_void, _c_long, _c_int, _c_int, _c_int,
+                   _c_int, _c_void)
+_splitk_norm = _sig("mvl_splitk_add_rms_norm", _c_void, _c_void, _c_void, _c_void, _c_void, _c_int,
+                    _c_int, _c_int, _c_long, _c_long, _c_float, _c_int, _c_void)
+
 _DT = {torch.bfloat16: 0, torch.float16: 1}
 
 
@@ -546,13 +554,18 @@ def mid_row_bucket(m: int) -> int:
     return 32 if m <= 32 else 64 if m <= 64 else 128 if m <= 128 else 256
 
 
-def mid_gemm_choice(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False):
+def mid_gemm_choice(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False,
+                    to_norm: bool = False):
     """The tuned configuration for this call, or None when the library GEMM is to be used
-    (unmeasured shapes included: the kernel only runs where it was seen to win)."""
+    (unmeasured shapes included: the kernel only runs where it was seen to win).  ``to_norm``:
+    the entry measured with the partial sums left to the norm kernel that follows (key
+    ``"norm"`` in place of the SwiGLU flag), falling back to the plain entry."""
     if x.dim() != 2 or x.shape[0] <= SKINNY_MAX_ROWS or x.shape[0] > MID_MAX_ROWS:
         return None
     n, k = weight.shape
-    c = _MID_CHOICE.get((mid_row_bucket(x.shape[0]), n, k, swiglu))
+    b = mid_row_bucket(x.shape[0])
+    key = (b, n, k, "norm") if to_norm and (b, n, k, "norm") in _MID_CHOICE else (b, n, k, swiglu)
+    c = _MID_CHOICE.get(key)
     if c is None or not mid_gemm_ok(x, weight, swiglu):
         return None
     return c
@@ -560,15 +573,21 @@ def mid_gemm_choice(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False)
 
 def mid_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                swiglu: bool = False, bn: int = 128, splits: int = 1, nt: bool = True,
-               bm: Optional[int] = None) -> torch.Tensor:
+               bm: Optional[int] = None, defer: bool = False):
     """``x @ weight.T (+ bias)`` (``swiglu``: ``silu(gate) * up`` of the fused weight) for up to
     256 rows with the weight-streaming MFMA kernel; ``splits`` > 1 slices K over workgroups
-    (fp32 partial sums in a scratch buffer, summed by a second kernel)."""
+    (fp32 partial sums in a scratch buffer, summed by a second kernel).  ``defer`` (with a K
+    split, no SwiGLU) returns the slices unsummed as ``SplitKPartials`` for a norm to consume."""
     M, K = x.shape
     N = weight.shape[0]
     if not mid_gemm_ok(x, weight, swiglu):
         raise ValueError(f"mid_linear cannot take x {tuple(x.shape)} / weight {tuple(weight.shape)}")
     bm = bm or mid_row_tile(M)
+    if defer and not swiglu and splits > 1 and (eff := _mid_eff_splits(K, splits)) > 1:
+        ws = torch.empty((eff, M, N), dtype=torch.float32, device=x.device)
+        _check(_mid(x.data_ptr(), x.stride(0), weight.data_ptr(), None, None, 0, ws.data_ptr(),
+                    M, N, K, 0, bm, bn, splits, int(nt), _dt(x), _stream()), "mid_gemm")
+        return SplitKPartials(ws, bias, x.dtype)
     out = torch.empty((M, N // 2 if swiglu else N), dtype=x.dtype, device=x.device)
     ws = (torch.empty(splits * M * N, dtype=torch.float32, device=x.device)
           if splits > 1 else None)
@@ -577,6 +596,48 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
                 ws.data_ptr() if ws is not None else None, M, N, K, int(swiglu), bm, bn, splits,
                 int(nt), _dt(x), _stream()), "mid_gemm")
     return out
+
+
+class SplitKPartials:
+    """The not yet summed K-slice partial products of a projection: ``ws`` [S, M, N] fp32 (+ the
+    bias still to be added).  Produced by ``mid_linear(..., defer=True)`` for a projection whose
+    output goes straight into (residual add +) RMSNorm; ``add_rms_norm`` sums the slices inside
+    the norm kernel, ``materialize`` gives the plain [M, N] tensor to any other consumer."""
+
+    __slots__ = ("ws", "bias", "dtype")
+
+    def __init__(self, ws: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype):
+        self.ws, self.bias, self.dtype = ws, bias, dtype
+
+    @property
+    def shape(self):
+        return self.ws.shape[1:]
+
+    def materialize(self) -> torch.Tensor:
+        S, M, N = self.ws.shape
+        out = torch.empty((M, N), dtype=self.dtype, device=self.ws.device)
+        _check(_mid_reduce(self.ws.data_ptr(), self.bias.data_ptr() if self.bias is not None
+                           else None, out.data_ptr(), N, M, N, S, _DT[self.dtype], _stream()),
+               "mid_reduce")
+        return out
+
+    def add_rms_norm(self, residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float):
+        """``(rms_norm(r) * weight, r)`` with ``r = sum of the slices (+ bias) + residual``;
+        ``residual`` is updated in place and returned as ``r``."""
+        if residual is None:
+            r = self.materialize()
+            return rms_norm(r, weight, eps), r
+        S, M, N = self.ws.shape
+        if (residual.shape != (M, N) or residual.dtype != self.dtype or residual.stride(1) != 1
+                or residual.stride(0) % 8 or residual.data_ptr() % 16 or N % 8 or N > 32768):
+            return add_rms_norm(self.materialize(), residual, weight, eps)
+        w = weight if weight.dtype == self.dtype else weight.to(self.dtype)
+        out = torch.empty((M, N), dtype=self.dtype, device=self.ws.device)
+        _check(_splitk_norm(self.ws.data_ptr(), self.bias.data_ptr() if self.bias is not None
+                            else None, residual.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, S,
+                            residual.stride(0), N, eps, _DT[self.dtype], _stream()),
+               "splitk_add_rms_norm")
+        return out, residual
 
 
 def _graph_time_ms(fn, x, weights, reps: int) -> float:
@@ -602,10 +663,13 @@ def _graph_time_ms(fn, x, weights, reps: int) -> float:
 
 
 def tune_mid_gemm(weights, swiglu: bool = False, rows=MID_ROW_BUCKETS,
-                  margin: float = 0.97) -> dict:
+                  margin: float = 0.97, to_norm: bool = False) -> dict:
     """For one projection (same-shaped matrices of several layers, cycled so that reads stay
     cold): time the library GEMM (+ activation kernel) against every candidate configuration
-    of the mid-batch kernel at the top of each row bucket and record the winner.  Returns
+    of the mid-batch kernel at the top of each row bucket and record the winner.  ``to_norm``
+    (projections whose output goes into residual add + RMSNorm): both sides are timed together
+    with that norm, the kernel side with its K-slice sum folded into it, and the winner is
+    recorded under the ``"norm"`` key.  Returns
     {rows: (library us, best kernel us or None, (bn, splits, nt) or None)}."""
     import torch.nn.functional as F
     weights = list(weights)
@@ -615,22 +679,33 @@ def tune_mid_gemm(weights, swiglu: bool = False, rows=MID_ROW_BUCKETS,
     if not mid_gemm_ok(torch.zeros(64, k, dtype=dtype, device=dev), weights[0], swiglu) \
             or n * k * 2 < (1 << 20):
         return out
+    assert not (to_norm and swiglu)
     reps = max(1, min(4, -(-(640 << 20) // (n * k * 2 * len(weights)))))
+    gamma = torch.ones(n, dtype=dtype, device=dev)
 
     def lib(x, w):
         y = F.linear(x, w)
+        if to_norm:
+            return add_rms_norm(y, resid, gamma, 1e-6)
         return silu_and_mul(y) if swiglu else y
 
     for m in rows:
         x = torch.randn(m, k, dtype=dtype, device=dev)
+        resid = torch.zeros(m, n, dtype=dtype, device=dev)
         t_lib = _graph_time_ms(lib, x, weights, reps)
         best, t_best = None, t_lib * margin
         for bn, sp in mid_gemm_candidates(m, n, k, swiglu):
-            t = _graph_time_ms(lambda xx, w: mid_linear(xx, w, None, swiglu, bn, sp, True),
-                               x, weights, reps)
+            def ker(xx, w):
+                y = mid_linear(xx, w, None, swiglu, bn, sp, True, defer=to_norm)
+                if not to_norm:
+                    return y
+                if isinstance(y, SplitKPartials):
+                    return y.add_rms_norm(resid, gamma, 1e-6)
+                return add_rms_norm(y, resid, gamma, 1e-6)
+            t = _graph_time_ms(ker, x, weights, reps)
             if t < t_best:
                 best, t_best = (bn, sp, True), t
-        _MID_CHOICE[(mid_row_bucket(m), n, k, swiglu)] = best
+        _MID_CHOICE[(mid_row_bucket(m), n, k, "norm" if to_norm else swiglu)] = best
         out[m] = (round(t_lib * 1e3, 1), round(t_best * 1e3, 1) if best else None, best)
     return out
 

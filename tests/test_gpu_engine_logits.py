@@ -210,7 +210,8 @@ def test_chunked_prefill_and_cached_prefix_logits(gpu, geom):
 
 def test_decode_logits_through_the_hand_written_gemm_kernels(gpu):
     """Decode batches of 24 (mid-batch MFMA kernel, forced for every projection incl. the
-    fused SwiGLU and a K split) and of 6 rows (weight-streaming kernel) against the oracle."""
+    fused SwiGLU, a K split, and K-slice sums folded into the following norm) and of 6 rows
+    (weight-streaming kernel) against the oracle."""
     from minivllm_amd.ops import hip
     geom = "16q8kv"
     g = _runner(_cfg(geom, max_num_sequences=32))
@@ -221,6 +222,9 @@ def test_decode_logits_through_the_hand_written_gemm_kernels(gpu):
     try:
         for (n, k, swi), choice in shapes.items():
             hip._MID_CHOICE[(32, n, k, swi)] = choice
+        # o / down projections with their K-slice sum left to the norm kernel that follows
+        hip._MID_CHOICE[(32, 1024, 2048, "norm")] = (64, 4, True)
+        hip._MID_CHOICE[(32, 1024, 3072, "norm")] = (128, 3, False)
         for n_seqs in (24, 6):
             rng = np.random.default_rng(10 + n_seqs)
             prompts = _prompts([int(x) for x in rng.integers(20, 300, size=n_seqs)], 11 + n_seqs)

@@ -397,6 +397,10 @@ _MID_SHAPES = [(4096, 1024), (1024, 2048), (1024, 3072),                    # 0.
                (768, 4096), (4096, 512), (4096, 1536), (1280, 5120), (5120, 3200)]   # TP=8 ranks
 
 
+def _rel(got, want):
+    return float((got.float() - want.float()).abs().max() / want.float().abs().max())
+
+
 def _mid_check(hip, dtype, M, N, K, bn, splits, swiglu=False, bias=False, strided=False):
     torch.manual_seed(31)
     if strided:
@@ -464,6 +468,80 @@ def test_mid_gemm_k_structure(hip):
         for sp in (1, 2):
             got = hip.mid_linear(x, w, bn=bn, splits=sp)
             assert torch.equal(got.float(), want.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M,N,K,bn,splits", [(24, 1024, 2048, 64, 4), (256, 4096, 4096, 128, 4),
+                                              (200, 4096, 12288, 128, 8), (64, 5120, 3200, 64, 3),
+                                              (130, 2560, 1024, 128, 16), (33, 32768, 512, 64, 2)])
+def test_mid_gemm_partials_into_add_rms_norm(hip, dtype, M, N, K, bn, splits):
+    """K-slice partials handed to the norm: (sum of slices + bias + residual, its RMSNorm)
+    against fp32, and against GEMM -> add_rms_norm through the separate kernels; the residual
+    is a strided view (rows of a wider buffer)."""
+    torch.manual_seed(M + N)
+    if N % bn:
+        pytest.skip("tile does not divide N")
+    x = torch.randn(M, K, device=DEV, dtype=dtype)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, device=DEV, dtype=dtype) if M % 2 == 0 else None
+    gamma = (1 + 0.1 * torch.randn(N, device=DEV)).to(dtype)
+    wide = torch.randn(M, N + 64, device=DEV, dtype=dtype)
+    resid = wide[:, :N]
+    resid0, beside = resid.clone(), wide[:, N:].clone()
+    parts = hip.mid_linear(x, w, bias, bn=bn, splits=splits, defer=True)
+    assert isinstance(parts, hip.SplitKPartials) and tuple(parts.shape) == (M, N)
+    assert parts.ws.shape[0] == min(splits, K // 64) or parts.ws.shape[0] < splits
+    y = x.float() @ w.float().T + (bias.float() if bias is not None else 0)
+    dense = parts.materialize()
+    assert _rel(dense, y) < 0.01
+    h, r = parts.add_rms_norm(resid, gamma, 1e-6)
+    assert r.data_ptr() == resid.data_ptr()
+    want_r = y + resid0.float()
+    assert _rel(r, want_r) < 0.01
+    rf = r.float()
+    want_h = rf * torch.rsqrt(rf.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma.float()
+    assert _rel(h, want_h) < 0.01
+    assert torch.equal(wide[:, N:], beside)                 # nothing written beside the view
+    # no residual: plain norm of the summed slices
+    h2, r2 = hip.mid_linear(x, w, bias, bn=bn, splits=splits, defer=True).add_rms_norm(
+        None, gamma, 1e-6)
+    assert _rel(r2, y) < 0.01 and r2.shape == (M, N)
+    # without a real K split the call returns the finished tensor
+    t = hip.mid_linear(x, w, bias, bn=bn, splits=1, defer=True)
+    assert torch.is_tensor(t) and _rel(t, y) < 0.01
+
+
+def test_ops_linear_to_norm_dispatch(hip):
+    """ops.linear(to_norm=True) hands partials to ops.norm_linear / ops.add_rms_norm only for
+    a shape whose tuned entry has a K split; everything else gets a tensor."""
+    from minivllm_amd import ops
+    M, N, K = 48, 1024, 2048
+    x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
+    w2 = (torch.randn(512, N, device=DEV) / math.sqrt(N)).to(torch.bfloat16)
+    gamma = torch.ones(N, device=DEV, dtype=torch.bfloat16)
+    saved = dict(hip._MID_CHOICE)
+    try:
+        hip._MID_CHOICE.clear()
+        assert torch.is_tensor(ops.linear(x, w, to_norm=True))
+        hip._MID_CHOICE[(64, N, K, "norm")] = (64, 4, True)
+        assert torch.is_tensor(ops.linear(x, w))                       # plain call: library
+        p = ops.linear(x, w, to_norm=True)
+        assert isinstance(p, hip.SplitKPartials)
+        resid = torch.randn(M, N, device=DEV, dtype=torch.bfloat16)
+        want_r = x.float() @ w.float().T + resid.float()
+        out, r = ops.norm_linear(p, resid.clone(), gamma, 1e-6, w2)
+        assert _rel(r, want_r) < 0.01
+        nf = want_r * torch.rsqrt(want_r.pow(2).mean(-1, keepdim=True) + 1e-6)
+        assert _rel(out, nf @ w2.float().T) < 0.02
+        h, r = ops.add_rms_norm(ops.linear(x, w, to_norm=True), resid.clone(), gamma, 1e-6)
+        assert _rel(h, nf) < 0.01
+        assert _rel(ops.rms_norm(ops.linear(x, w, to_norm=True), gamma, 1e-6),
+                    (lambda y: y * torch.rsqrt(y.pow(2).mean(-1, keepdim=True) + 1e-6))(
+                        x.float() @ w.float().T)) < 0.01
+    finally:
+        hip._MID_CHOICE.clear()
+        hip._MID_CHOICE.update(saved)
 
 
 def test_mid_gemm_rejects(hip):
