@@ -16,6 +16,7 @@ import torch
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                          "_hip_kernels.so")
+_LIB_PATH = os.environ.get("MINIVLLM_HIP_LIB", _LIB_PATH)        # kernel experiments: another build
 if not os.path.exists(_LIB_PATH):
     raise ImportError(
         f"{_LIB_PATH} is missing: build the HIP kernels first with "

@@ -289,6 +289,39 @@ def test_paged_prefill_with_prefix(hip, dtype, bs, hq, hkv, d):
     close(got, want, dtype)
 
 
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (16, 8, 128), (8, 1, 128), (16, 8, 64)])
+def test_prefill_many_uneven_sequences(hip, hq, hkv, d):
+    """Several thousand workgroups over 44 sequences of uneven length (Q tiles without rows,
+    single-tile sequences and multi-tile ones side by side), packed and paged with cached
+    prefixes; a second launch must give the same bits."""
+    torch.manual_seed(40 + hq)
+    dtype = torch.bfloat16
+    rng = torch.Generator().manual_seed(7)
+    B = 44
+    q_lens = [int(x) for x in torch.randint(1, 700, (B,), generator=rng)]
+    q_lens[3], q_lens[17], q_lens[30] = 1, 64, 129
+    prefix = [int(x) for x in torch.randint(0, 3, (B,), generator=rng) * 150]
+    k_lens = [a + b for a, b in zip(q_lens, prefix)]
+    scale = 1.0 / math.sqrt(d)
+    T = sum(q_lens)
+    q = torch.randn(T, hq, d, device=DEV, dtype=dtype)
+    k = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    want = ref.flash_attention_prefill(q, k, v, cu, scale)
+    got = hip.flash_attention_prefill(q, k, v, cu, scale)
+    close(got, want, dtype)
+    again = hip.flash_attention_prefill(q, k, v, cu, scale, max_seqlen=max(q_lens))
+    assert torch.equal(got, again)
+    kk = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    vv = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(kk, vv, k_lens, 256, hkv, d, dtype)
+    ck = torch.tensor([0] + list(torch.tensor(k_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    want = ref.paged_attention_prefill(q, kc, vc, cu, ck, tables, scale)
+    got = hip.paged_attention_prefill(q, kc, vc, cu, ck, tables, scale)
+    close(got, want, dtype)
+
+
 def test_flash_prefill_long_and_softmax_rescale(hip):
     """4k tokens (many KV tiles) with a spiked key late in the sequence, which forces the
     running-max rescale branch of the online softmax on rows that already accumulated."""
