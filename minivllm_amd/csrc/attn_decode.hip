@@ -11,7 +11,8 @@
 //    group), so every K/V byte is fetched once per sequence, not once per query head;
 //  * grid = (context splits, KV heads, sequences); each wave walks its own 32-token tiles
 //    and keeps a private online-softmax state, the 4 waves and then the splits are merged
-//    flash-decoding style, so small batches still fill 256 CUs;
+//    flash-decoding style (the splits by whichever of their workgroups finishes last, inside
+//    this kernel), so small batches still fill 256 CUs;
 //  * a tile is fetched with 16-byte-per-lane coalesced loads (a (block, kv-head) slab is
 //    contiguous in the engine's cache layout), staged through wave-private LDS (no
 //    workgroup barrier in the loop) and prefetched one tile ahead in registers, block-table
@@ -35,6 +36,17 @@ namespace {
 
 constexpr int kTile = 32;          // tokens per wave iteration
 constexpr int kWaves = 4;
+
+// Device-scope ("agent") relaxed accesses to global memory: stores are written through to
+// where every XCD sees them, loads are served from there.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) int gint;
+__device__ __forceinline__ void st_agent(float* p, float v) {
+    __hip_atomic_store((gfloat*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float ld_agent(const float* p) {
+    return __hip_atomic_load((gfloat*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Byte offset of 16-byte chunk `ch` of row `row` in a wave's [32 rows][CPR chunks] tile image.
 // The XOR pattern is chosen for the lane groups in which the LDS services this kernel's
@@ -87,7 +99,7 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         const char* __restrict__ k_cache, const char* __restrict__ v_cache,
         long cs_b, long cs_t, long cs_h, const int* __restrict__ block_tables, int bt_stride,
         const int* __restrict__ context_lens, uint16_t* __restrict__ out, long o_stride_b,
-        long o_stride_h, float* __restrict__ part_acc, float* __restrict__ part_ml,
+        long o_stride_h, float* part_acc, float* part_ml, int* tickets,
         float scale_log2, int Hq, int Hkv, int bs_log2, int nsplit) {
     using DT = DType<CODE>;
     using vec8 = typename DT::vec8;
@@ -317,55 +329,72 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
             const float r = l > 0.f ? o / l : 0.f;
             out[b * o_stride_b + head * o_stride_h + d] = DT::from_float(r);
         } else {
+            // partial results cross to another workgroup, possibly on another XCD (private
+            // L2): device-scope (write-through) stores, read back below by device-scope loads
             const long pi = ((long)b * Hq + head) * nsplit + split;
-            part_acc[pi * D + d] = o;
-            if (d == 0) { part_ml[pi * 2] = M; part_ml[pi * 2 + 1] = l; }
+            st_agent(part_acc + pi * D + d, o);
+            if (d == 0) { st_agent(part_ml + pi * 2, M); st_agent(part_ml + pi * 2 + 1, l); }
         }
     }
-}
+    if (nsplit == 1) return;
 
-// Merge the context splits: grid (Hq, B), D threads.  The (max, sum) pairs are fetched by
-// one lane each and the partial outputs with all loads of a group of 8 splits in flight at
-// once: the kernel is a chain of dependent memory round trips otherwise, and at small batch
-// it sits on the critical path of every layer.
-template <int CODE, int D>
-__global__ void decode_reduce_kernel(const float* __restrict__ part_acc,
-                                     const float* __restrict__ part_ml,
-                                     uint16_t* __restrict__ out, long o_stride_b,
-                                     long o_stride_h, int Hq, int nsplit) {
-    __shared__ float s_f[64];
-    __shared__ float s_l;
-    const int head = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const long base = ((long)b * Hq + head) * nsplit;
-    if (d < 64) {                                       // nsplit <= 64 (checked by the launcher)
-        const float ms = d < nsplit ? part_ml[(base + d) * 2] : -INFINITY;
-        const float ls = d < nsplit ? part_ml[(base + d) * 2 + 1] : 0.f;
-        const float M = wave_max(ms);
-        const float f = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ms - M);
-        s_f[d] = f;
-        const float l = wave_sum(ls * f);
-        if (d == 0) s_l = l;
+    // ---- merge of the context splits by the workgroup that finishes last.  Every split of a
+    // (sequence, head group) takes a ticket once its partial results are out: each wave waits
+    // for its write-through stores, the workgroup meets, one lane adds to the counter.  The
+    // holder of the last ticket resets the counter for the next launch and combines all
+    // partials, which it reads with device-scope loads (they bypass this CU's L1 and this
+    // XCD's L2, so no cache invalidate is needed; a full release/acquire fence pair here cost
+    // more than the separate merge kernel it replaces).
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        gint* ctr = (gint*)(tickets + (long)b * gridDim.y + blockIdx.y);
+        const int t = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = t == nsplit - 1;
+        if (s_last) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
-    float o = 0.f;
-    int s = 0;
-    for (; s + 8 <= nsplit; s += 8) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = part_acc[(base + s + j) * D + d];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) o += v[j] * s_f[s + j];
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");     // no instruction: keeps the loads below
+
+    float* s_f = reinterpret_cast<float*>(smem);       // [16 heads][64 splits] weights of the splits
+    float* s_l = s_f + 16 * 64;                        // [16 heads] merged normalisers
+    for (int c = w; c < nheads; c += kWaves) {         // lane = split (nsplit <= 64)
+        const long base = ((long)b * Hq + head0 + c) * nsplit;
+        const float ms = lane < nsplit ? ld_agent(part_ml + (base + lane) * 2) : -INFINITY;
+        const float ls = lane < nsplit ? ld_agent(part_ml + (base + lane) * 2 + 1) : 0.f;
+        const float M = wave_max(ms);
+        const float f = (ms == -INFINITY) ? 0.f : __builtin_amdgcn_exp2f(ms - M);
+        s_f[c * 64 + lane] = f;
+        const float l = wave_sum(ls * f);
+        if (lane == 0) s_l[c] = l;
     }
-    for (; s < nsplit; ++s) o += part_acc[(base + s) * D + d] * s_f[s];
-    const float l = s_l;
-    out[b * o_stride_b + head * o_stride_h + d] = DType<CODE>::from_float(l > 0.f ? o / l : 0.f);
+    __syncthreads();
+    for (int e = threadIdx.x; e < nheads * D; e += 256) {
+        const int c = e / D, d = e - c * D;
+        const long base = ((long)b * Hq + head0 + c) * nsplit;
+        const float* sf = s_f + c * 64;
+        float o = 0.f;
+        int s = 0;
+        for (; s + 8 <= nsplit; s += 8) {              // 8 loads in flight: a chain of round trips otherwise
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = ld_agent(part_acc + (base + s + j) * D + d);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o += v[j] * sf[s + j];
+        }
+        for (; s < nsplit; ++s) o += ld_agent(part_acc + (base + s) * D + d) * sf[s];
+        const float l = s_l[c];
+        out[b * o_stride_b + (head0 + c) * o_stride_h + d] = DT::from_float(l > 0.f ? o / l : 0.f);
+    }
 }
 
 template <int CODE, int D, bool KV8>
 int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void* vc, long csb,
                   long cst, long csh, const int* bt, int bt_stride, const int* ctx, void* out,
-                  long osb, long osh, float* part_acc, float* part_ml, float scale, int B, int Hq,
-                  int Hkv, int block_size, int nsplit, hipStream_t st) {
+                  long osb, long osh, float* part_acc, float* part_ml, int* tickets, float scale,
+                  int B, int Hq, int Hkv, int block_size, int nsplit, hipStream_t st) {
     int bs_log2 = 0;
     while ((1 << bs_log2) < block_size) ++bs_log2;
     // the kernel forms in-block byte offsets in 32 bits (token stride through a 24-bit multiply)
@@ -379,38 +408,36 @@ int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void*
     const size_t lds = (size_t)kWaves * 2 * kTile * D * 2;
     paged_decode_kernel<CODE, D, KV8><<<grid, 256, lds, st>>>(
         (const uint16_t*)q, qsb, qsh, (const char*)kc, (const char*)vc, csb, cst, csh, bt,
-        bt_stride, ctx, (uint16_t*)out, osb, osh, part_acc, part_ml, scale * kLog2e, Hq, Hkv,
-        bs_log2, nsplit);
-    int rc = MVL_CHECK_LAUNCH();
-    if (rc != 0 || nsplit == 1) return rc;
-    decode_reduce_kernel<CODE, D><<<dim3(Hq, B), D, 0, st>>>(part_acc, part_ml, (uint16_t*)out,
-                                                            osb, osh, Hq, nsplit);
+        bt_stride, ctx, (uint16_t*)out, osb, osh, part_acc, part_ml, tickets, scale * kLog2e, Hq,
+        Hkv, bs_log2, nsplit);
     return MVL_CHECK_LAUNCH();
 }
 
 }  // namespace
 
 // q [B, Hq, D] (strides in elements), caches addressed by (block, token, kv head) strides in
-// cache elements, block_size a power of two, part_* workspaces needed only when nsplit > 1:
-// part_acc [B*Hq*nsplit*D] fp32, part_ml [B*Hq*nsplit*2] fp32.  kv_fp8 != 0: the caches hold
-// OCP fp8 e4m3 bytes instead of values of the query's dtype.
+// cache elements, block_size a power of two, workspaces needed only when nsplit > 1:
+// part_acc [B*Hq*nsplit*D] fp32, part_ml [B*Hq*nsplit*2] fp32, tickets [B * Hkv * ceil(G/16)]
+// ints that are zero at the first launch and shared with no launch that may run at the same
+// time (the kernel leaves them zero).  kv_fp8 != 0: the caches hold OCP fp8 e4m3 bytes instead
+// of values of the query's dtype.
 extern "C" int mvl_paged_attention_decode(
         const void* q, long q_stride_b, long q_stride_h, const void* k_cache, const void* v_cache,
         long cs_b, long cs_t, long cs_h, const int* block_tables, int bt_stride,
         const int* context_lens, void* out, long o_stride_b, long o_stride_h, float* part_acc,
-        float* part_ml, float scale, int B, int Hq, int Hkv, int D, int block_size, int nsplit,
-        int dtype, int kv_fp8, void* stream) {
+        float* part_ml, int* tickets, float scale, int B, int Hq, int Hkv, int D, int block_size,
+        int nsplit, int dtype, int kv_fp8, void* stream) {
     if (B == 0) return 0;
     if ((D != 64 && D != 128) || Hq % Hkv != 0 || (block_size & (block_size - 1)) || nsplit < 1 ||
         nsplit > 64)
         return -1;
-    if (nsplit > 1 && (part_acc == nullptr || part_ml == nullptr)) return -2;
+    if (nsplit > 1 && (part_acc == nullptr || part_ml == nullptr || tickets == nullptr)) return -2;
     auto st = (hipStream_t)stream;
 #define MVL_DEC(CODE, DD, K8)                                                                   \
     return launch_decode<CODE, DD, K8>(q, q_stride_b, q_stride_h, k_cache, v_cache, cs_b, cs_t,    \
                                        cs_h, block_tables, bt_stride, context_lens, out,           \
-                                       o_stride_b, o_stride_h, part_acc, part_ml, scale, B, Hq,    \
-                                       Hkv, block_size, nsplit, st)
+                                       o_stride_b, o_stride_h, part_acc, part_ml, tickets, scale,  \
+                                       B, Hq, Hkv, block_size, nsplit, st)
     if (kv_fp8) {
         if (dtype == 0) { if (D == 128) MVL_DEC(0, 128, true); else MVL_DEC(0, 64, true); }
         else            { if (D == 128) MVL_DEC(1, 128, true); else MVL_DEC(1, 64, true); }

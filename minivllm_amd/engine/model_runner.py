@@ -229,6 +229,12 @@ class ModelRunner:
     def _init_buffers(self) -> None:
         cfg = self.cfg
         mb, MB = self.max_bs, self.max_blocks_per_seq
+        if self.on_gpu:
+            # scratch the decode kernel needs to exist before any graph is captured
+            from minivllm_amd.ops import hip
+            groups = -(-(cfg.model.num_heads // cfg.model.num_kv_heads) // 16)
+            hip.decode_ticket_words(self.device, mb * max(1, cfg.model.num_kv_heads // self.world_size)
+                                    * groups)
         # decode: fixed layout so that graphs can bake the addresses in
         self._dec_off = {}
         off = 0

@@ -52,8 +52,8 @@ _sample = _sig("mvl_sample", _c_void, _c_long, _c_int, _c_int, _c_int, _c_int, _
                _c_void, _c_void, _c_void, _c_int, _c_int, _c_void, _c_void, _c_void)
 _decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
                _c_long, _c_long, _c_void, _c_int, _c_void, _c_void, _c_long, _c_long, _c_void,
-               _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-               _c_void)
+               _c_void, _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
+               _c_int, _c_void)
 _prefill = _sig("mvl_flash_attention_prefill", _c_void, _c_long, _c_long, _c_void, _c_void,
                 _c_long, _c_long, _c_long, _c_void, _c_long, _c_long, _c_void, _c_void, _c_void,
                 _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -331,11 +331,36 @@ def decode_num_splits(batch: int, num_kv_heads: int, max_context_len: Optional[i
     return n
 
 
+# The decode kernel merges its context splits in the workgroup that finishes last; the tickets
+# that decide which one that is are zero between launches (the kernel resets them), so one
+# buffer per device serves every launch that cannot overlap another one on that device.
+_DECODE_TICKETS: dict = {}
+DECODE_TICKET_WORDS = 1 << 16
+
+
+def decode_ticket_words(device: torch.device, need: int) -> torch.Tensor:
+    """The device's ticket buffer (at least ``need`` ints).  It is allocated on first use, which
+    must not happen inside a graph capture (the memory would belong to the graph's pool): the
+    model runner calls this at start-up."""
+    idx = device.index if device.index is not None else torch._C._cuda_getDevice()
+    buf = _DECODE_TICKETS.get(idx)
+    if buf is None or buf.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("the decode kernel's ticket buffer must exist before graph capture: "
+                               "call hip.decode_ticket_words(device, n) first")
+        buf = _DECODE_TICKETS[idx] = torch.zeros(max(need, DECODE_TICKET_WORDS), dtype=torch.int32,
+                                                 device=device)
+    return buf
+
+
 def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor,
                            block_tables: torch.Tensor, context_lens: torch.Tensor, scale: float,
                            max_context_len: Optional[int] = None,
                            num_splits: Optional[int] = None,
-                           out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           out: Optional[torch.Tensor] = None,
+                           tickets: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``tickets``: zeroed int32 scratch of B * Hkv * ceil(G / 16) words for callers that run
+    decode launches concurrently on several streams of one device (each stream its own)."""
     B, hq, d = q.shape
     hkv = k_cache.shape[2]
     bt, ctx = _i32(block_tables), _i32(context_lens)
@@ -350,12 +375,16 @@ def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torc
     if ns > 1:
         part_acc = torch.empty(B * hq * ns * d, dtype=torch.float32, device=q.device)
         part_ml = torch.empty(B * hq * ns * 2, dtype=torch.float32, device=q.device)
-        pa, pm = part_acc.data_ptr(), part_ml.data_ptr()
+        need = B * hkv * ((hq // hkv + 15) // 16)
+        if tickets is None:
+            tickets = decode_ticket_words(q.device, need)
+        assert tickets.dtype == torch.int32 and tickets.numel() >= need and tickets.is_contiguous()
+        pa, pm, tk = part_acc.data_ptr(), part_ml.data_ptr(), tickets.data_ptr()
     else:
-        pa = pm = None
+        pa = pm = tk = None
     _check(_decode(q.data_ptr(), qs_b, qs_h, k_cache.data_ptr(), v_cache.data_ptr(), sb, st, sh,
                    bt.data_ptr(), bt.stride(0), ctx.data_ptr(), out.data_ptr(), out.stride(0),
-                   out.stride(1), pa, pm, scale, B, hq, hkv, d, k_cache.shape[1], ns, _dt(q),
+                   out.stride(1), pa, pm, tk, scale, B, hq, hkv, d, k_cache.shape[1], ns, _dt(q),
                    _kv_fp8(k_cache), _stream()), "paged_attention_decode")
     return out
 

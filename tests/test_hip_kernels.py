@@ -217,6 +217,51 @@ def test_paged_decode(hip, dtype, hq, hkv, d, bs):
     close(got, want, dtype)
 
 
+def test_paged_decode_split_merge_tickets(hip):
+    """The context splits are merged by the workgroup that finishes last (a ticket per
+    (sequence, head group)).  Many back-to-back launches with different split counts and batch
+    sizes, eager and as replays of a captured graph: same bits every time, tickets back at zero."""
+    torch.manual_seed(81)
+    dtype, hq, hkv, d, bs = torch.bfloat16, 32, 8, 128, 256
+    lens = [1000, 31, 513, 2048, 77, 1, 300, 1500, 64]
+    k = torch.randn(sum(lens), hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(sum(lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(k, v, lens, bs, hkv, d, dtype)
+    q = torch.randn(len(lens), hq, d, device=DEV, dtype=dtype)
+    ctx = torch.tensor(lens, device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    want = ref.paged_attention_decode(q, kc, vc, tables, ctx, scale)
+    first = {}
+    for rep in range(30):
+        for ns in (2, 7, 16, 32, 64):
+            for nb in (len(lens), 3, 1):
+                got = hip.paged_attention_decode(q[:nb], kc, vc, tables[:nb], ctx[:nb], scale,
+                                                 num_splits=ns)
+                key = (ns, nb)
+                if key not in first:
+                    close(got, want[:nb], dtype)
+                    first[key] = got
+                else:
+                    assert torch.equal(got, first[key]), (rep, key)
+    torch.cuda.synchronize()
+    tickets = hip.decode_ticket_words(q.device, 1)
+    assert int(tickets.abs().sum()) == 0
+    out = torch.empty_like(q)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(4):                                   # several layers' worth per replay
+            hip.paged_attention_decode(q, kc, vc, tables, ctx, scale, num_splits=16, out=out)
+    for _ in range(20):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, first[(16, len(lens))])
+    assert int(tickets.abs().sum()) == 0
+    own = torch.zeros(len(lens) * hkv, dtype=torch.int32, device=DEV)      # caller-owned tickets
+    got = hip.paged_attention_decode(q, kc, vc, tables, ctx, scale, num_splits=16, tickets=own)
+    assert torch.equal(got, first[(16, len(lens))]) and int(own.abs().sum()) == 0
+
+
 def test_paged_decode_reference_layout_and_padding(hip):
     """Token-major cache (the layout the reference benchmark builds), strided q, and rows with
     context 0 (graph padding) which must come out as zeros without touching the table."""
