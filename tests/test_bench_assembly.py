@@ -41,6 +41,21 @@ def test_tensor_parallel_is_the_headline_at_the_one_gpu_batch():
     assert out["qwen3_32b_tp8_32k_prefill"]["prefill_tok_s"] == 120000.0
 
 
+def test_the_faster_all_reduce_plane_is_the_headline_and_named():
+    out, good = _assemble(_res(), _res(dec=60000.0), _res(dec=75000.0))
+    assert good and out["value"] == 75000.0 and out["config"]["all_reduce"] == "p2p"
+    assert out["config"]["parallelism"] == "tp8" and out["scaling"] == "strong"
+    assert out["tensor_parallel_rccl_allreduce"]["decode_tok_s"] == 60000.0
+    assert "tensor_parallel_p2p_allreduce" not in out
+    out, good = _assemble(_res(), _res(dec=60000.0), _res(dec=50000.0))
+    assert out["value"] == 60000.0 and out["config"]["all_reduce"] == "rccl"
+    assert out["tensor_parallel_p2p_allreduce"]["decode_tok_s"] == 50000.0
+    # RCCL phase failed, peer-to-peer phase delivered: still a TP headline
+    out, good = _assemble(_res(), {"error": "tp phase exceeded 600s"}, _res(dec=70000.0))
+    assert good and out["value"] == 70000.0 and out["config"]["all_reduce"] == "p2p"
+    assert "error" in out["tensor_parallel_rccl_allreduce"] and "headline_fallback" not in out
+
+
 def test_data_parallel_stands_in_only_as_a_marked_fallback():
     out, good = _assemble(_res(), {"error": "tp phase child exited with code 1"}, None)
     assert good and out["value"] == 8 * 18000.0 and out["scaling"] == "weak"
