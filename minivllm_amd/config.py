@@ -196,8 +196,8 @@ class EngineConfig:
     custom_all_reduce: bool = False
     # steady-state decode: enqueue step n + 1 (inputs derived on the device from step n's
     # samples) before reading step n's tokens back, so the GPU does not idle while the host
-    # post-processes; single-rank engines only, and on a GPU only with MINIVLLM_PRELAUNCH_GPU=1
-    # (see ModelRunner._can_prelaunch)
+    # post-processes; single-rank engines with graph-replayed decode steps only
+    # (ModelRunner._can_prelaunch; MINIVLLM_NO_PRELAUNCH=1 switches it off)
     decode_prelaunch: bool = True
     # tuning knobs of the multi-GPU path that have no measurement on real xGMI links behind them
     # yet (None = module default, also settable through the environment, see the modules):

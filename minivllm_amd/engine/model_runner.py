@@ -608,15 +608,8 @@ class ModelRunner:
             return False
         if os.environ.get("MINIVLLM_NO_PRELAUNCH") == "1":
             return False
-        if self.on_gpu:
-            # Not enabled on the GPU by default: the first run of the GPU test suite with this
-            # path active ended in a device memory fault whose cause has not been found (the
-            # same control flow, replayed on the CPU with every staging block validated, is
-            # clean: tests/test_decode_launch_ahead.py).  MINIVLLM_PRELAUNCH_GPU=1 opts in.
-            if os.environ.get("MINIVLLM_PRELAUNCH_GPU") != "1":
-                return False
-            if self._graph_bucket(b.num_seqs) is None:
-                return False             # eager GPU steps are host-bound anyway
+        if self.on_gpu and self._graph_bucket(b.num_seqs) is None:
+            return False                 # eager GPU steps are host-bound anyway
         # the step after this one reads position = context length: inside the model's tables?
         return int(b.arrays["context_lens"].max()) + 1 < self.cfg.max_model_length
 
@@ -764,6 +757,10 @@ class ModelRunner:
         put("context_lens", a["context_lens"], 0)
         put("temperatures", a["temperatures"].astype(np.float32).view(np.int32), 0)
         host[self._dec_off["misc"][0]] = b.step
+        # Which table rows a staging block already holds is tracked by a counter, never by the
+        # identity of the numpy array: a freed array's address is handed to the next one, and a
+        # block taken for up to date on that ground ships another batch's tables (entries of
+        # -1 under a live context length: the decode kernel then reads far outside the cache).
         if not b.tables_unchanged:
             self._tables_version += 1     # a new set of block tables (every rank counts alike)
         key = (padded_bs, B, self._tables_version)

@@ -432,9 +432,6 @@ def test_decode_steps_launched_ahead_do_not_change_outputs(gpu):
     """Steady-state decode enqueues step n + 1 before step n's tokens are read back.  With
     requests of different lengths (rows drop out one by one), a stop token (a finish the host
     cannot foresee) and an abort in mid-flight, greedy outputs must equal the plain loop's."""
-    if os.environ.get("MINIVLLM_PRELAUNCH_GPU") != "1":
-        pytest.skip("launch-ahead decode is opt-in on the GPU (MINIVLLM_PRELAUNCH_GPU=1): its "
-                    "first GPU run ended in a device memory fault that is not understood yet")
     from minivllm_amd.engine.llm_engine import LLMEngine
     prompts = _prompts(8, lo=20, hi=120, seed=9)
     lens = [5, 40, 17, 33, 40, 9, 28, 40]
