@@ -46,6 +46,13 @@ struct PrefillArgs {
     float scale_log2;
     int B, Hq, Hkv, n_qtiles;
     int total_wg;
+    // optional: q holds the raw projection and the kernel applies the per-head RMSNorm (weight
+    // q_w, may be null) and the rotary embedding (fp32 table [position][D]: cos of the D/2
+    // pairs, then sin) to its Q rows while it loads them; null cos_sin: q is used as it is
+    const int* positions;                      // [total tokens], indexed like q
+    const float* cos_sin;
+    const uint16_t* q_w;
+    float eps;
 #ifdef MVL_PREFILL_PROBE
     unsigned long long* probe;                 // [total_wg][8] timestamps (tools/native/prefill_phase_probe.hip)
 #endif
@@ -107,6 +114,48 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s)
             qfrag[s] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(qp + 16 * s + 8 * hh));
+    }
+    // ---- q/k-norm + RoPE of the Q rows, fused here: a Q row is read by exactly one workgroup,
+    //      so the projection's output never has to be rewritten in place and read again (K is
+    //      shared by many workgroups and is transformed by the store kernel beforehand).  Pairs
+    //      (e, e + D/2) of a row sit in one lane: fragments s and s + KSTEPS/2.
+    if (a.cos_sin != nullptr) {
+        float f[KSTEPS][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            unpack8<CODE>(__builtin_bit_cast(u32x4_t, qfrag[s]), f[s]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += f[s][i] * f[s][i];
+        }
+        ss += __shfl_xor(ss, 32, 64);                    // the other half of the row
+        if (a.q_w != nullptr) {
+            const float rstd = rsqrtf(ss / (float)D + a.eps);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                float wv[8];
+                unpack8<CODE>(*reinterpret_cast<const u32x4_t*>(a.q_w + 16 * s + 8 * hh), wv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[s][i] *= rstd * wv[i];
+            }
+        }
+        const float* cs = a.cos_sin + (long)a.positions[q_start + my_q_c] * D;
+#pragma unroll
+        for (int s = 0; s < KSTEPS / 2; ++s) {
+            const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh);
+            const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh + 4);
+            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh);
+            const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh + 4);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float c = i < 4 ? c0[i] : c1[i - 4], sn = i < 4 ? s0[i] : s1[i - 4];
+                const float x1 = f[s][i], x2 = f[s + KSTEPS / 2][i];
+                f[s][i] = x1 * c - x2 * sn;
+                f[s + KSTEPS / 2][i] = x1 * sn + x2 * c;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) qfrag[s] = __builtin_bit_cast(vec8, pack8<CODE>(f[s]));
     }
     const int my_pos = my_q + pos_off;                   // last key this row may see
     const int wave_min_pos = q0 + 32 * w + pos_off;
@@ -312,6 +361,7 @@ int launch_prefill(PrefillArgs a, hipStream_t st) {
 
 }  // namespace
 
+// positions / cos_sin / q_w / eps: see PrefillArgs (cos_sin null: q is already transformed).
 // paged == 0: k/v are packed [T, Hkv, D] tensors (token stride k_stride_t, head stride
 // k_stride_h), cu_k may equal cu_q.  paged == 1: k/v are caches addressed by
 // (block stride cs_b, token stride k_stride_t, head stride k_stride_h) through block_tables.
@@ -320,7 +370,7 @@ extern "C" int mvl_flash_attention_prefill(
         long k_stride_t, long k_stride_h, long cs_b, void* out, long o_stride_t, long o_stride_h,
         const int* cu_q, const int* cu_k, const int* block_tables, int bt_stride, int block_size,
         float scale, int B, int Hq, int Hkv, int D, int max_q_len, int paged, int dtype,
-        void* stream) {
+        const int* positions, const float* cos_sin, const void* q_w, float eps, void* stream) {
     if (B == 0 || max_q_len <= 0) return 0;
     if ((D != 64 && D != 128) || Hq % Hkv != 0) return -1;
     if (paged && (block_size & (block_size - 1))) return -1;
@@ -337,6 +387,8 @@ extern "C" int mvl_flash_attention_prefill(
     a.B = B; a.Hq = Hq; a.Hkv = Hkv;
     a.n_qtiles = (max_q_len + kBM - 1) / kBM;
     a.total_wg = B * Hq * a.n_qtiles;
+    if (cos_sin != nullptr && positions == nullptr) return -1;
+    a.positions = positions; a.cos_sin = cos_sin; a.q_w = (const uint16_t*)q_w; a.eps = eps;
     auto st = (hipStream_t)stream;
 #define MVL_PRE(CODE, DD)                                                         \
     return paged ? launch_prefill<CODE, DD, true>(a, st) : launch_prefill<CODE, DD, false>(a, st)

@@ -192,7 +192,7 @@ __global__ void qk_norm_rope_store_kernel(
         const float* __restrict__ cos_sin, const uint16_t* __restrict__ qw,
         const uint16_t* __restrict__ kw, float eps, int Hq, int Hkv,
         uint16_t* k_cache, uint16_t* v_cache, long c_stride_b, long c_stride_t, long c_stride_h,
-        int block_size, const int* __restrict__ slot_mapping, long total_rows) {
+        int block_size, const int* __restrict__ slot_mapping, long total_rows, int first_head) {
     constexpr int LPR = D / 8;
     constexpr int RPW = 64 / LPR;                // rows per wave
     const int lane = threadIdx.x & 63;
@@ -200,9 +200,11 @@ __global__ void qk_norm_rope_store_kernel(
     const long wave = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const long row = wave * RPW + lane / LPR;
     const bool active = row < total_rows;
-    const int H = Hq + 2 * Hkv;
+    // first_head = Hq: only the K and V heads are visited (the Q rows are left to the prefill
+    // attention kernel, which transforms them as it loads them)
+    const int H = Hq + 2 * Hkv - first_head;
     const long t = active ? row / H : 0;
-    const int h = active ? (int)(row - t * H) : 0;
+    const int h = first_head + (active ? (int)(row - t * H) : 0);
     uint16_t* p = qkv + t * qkv_stride + (long)h * D;
     u32x2_t a = {0, 0}, b = {0, 0};
     if (active) {
@@ -273,10 +275,11 @@ extern "C" int mvl_qk_norm_rope_store(void* qkv, long qkv_stride, const int* pos
                                       float eps, long T, int Hq, int Hkv, int D, void* k_cache,
                                       void* v_cache, long c_stride_b, long c_stride_t,
                                       long c_stride_h, int block_size, const int* slot_mapping,
-                                      int dtype, int kv_fp8, void* stream) {
+                                      int dtype, int kv_fp8, int skip_q, void* stream) {
     if (D != 64 && D != 128) return -1;
     if (T == 0) return 0;
-    const long rows = T * (Hq + 2 * Hkv);
+    const int first_head = skip_q ? Hq : 0;
+    const long rows = T * (Hq + 2 * Hkv - first_head);
     const int rpw = 64 / (D / 8);
     const int threads = 256;
     const long waves = (rows + rpw - 1) / rpw;
@@ -286,7 +289,7 @@ extern "C" int mvl_qk_norm_rope_store(void* qkv, long qkv_stride, const int* pos
     qk_norm_rope_store_kernel<CODE, DD, K8><<<(unsigned)blocks, threads, 0, st>>>(             \
         (uint16_t*)qkv, qkv_stride, positions, cos_sin, (const uint16_t*)qw,                   \
         (const uint16_t*)kw, eps, Hq, Hkv, (uint16_t*)k_cache, (uint16_t*)v_cache, c_stride_b, \
-        c_stride_t, c_stride_h, block_size, slot_mapping, rows)
+        c_stride_t, c_stride_h, block_size, slot_mapping, rows, first_head)
     if (kv_fp8) {
         if (dtype == 0) { if (D == 128) MVL_LAUNCH_ROPE(0, 128, true); else MVL_LAUNCH_ROPE(0, 64, true); }
         else            { if (D == 128) MVL_LAUNCH_ROPE(1, 128, true); else MVL_LAUNCH_ROPE(1, 64, true); }

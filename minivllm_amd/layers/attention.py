@@ -18,6 +18,7 @@ the engine allocates them with a head-major physical order so that one
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import torch
@@ -58,6 +59,10 @@ def paged_attention_decode(query: torch.Tensor, k_cache: torch.Tensor, v_cache: 
 
 
 # --------------------------------------------------------------------- layer
+# MINIVLLM_NO_Q_FUSE=1: q-norm + RoPE of the Q rows stay in the store kernel (for A/B timing)
+_FUSE_Q_ROPE = os.environ.get("MINIVLLM_NO_Q_FUSE", "0") != "1"
+
+
 class Attention(nn.Module):
     def __init__(self, num_heads: int, head_dim: int, scale: float = 1.0,
                  num_kv_heads: Optional[int] = None, block_size: Optional[int] = None):
@@ -71,12 +76,21 @@ class Attention(nn.Module):
         self.k_cache: Optional[torch.Tensor] = None
         self.v_cache: Optional[torch.Tensor] = None
 
+    @staticmethod
+    def fuses_q_rope(ctx, q: torch.Tensor) -> bool:
+        """True for the steps whose attention transforms raw Q rows itself (``q_rope``): pure
+        prefill steps on the GPU.  Decode rows (decode steps, the riders of a mixed step) go
+        through the decode kernel, which expects finished queries."""
+        return bool(_FUSE_Q_ROPE and ctx.is_prefill and not ctx.num_decode_seqs and q.is_cuda)
+
     def forward(self, q: torch.Tensor, k: Optional[torch.Tensor] = None,
-                v: Optional[torch.Tensor] = None) -> torch.Tensor:
+                v: Optional[torch.Tensor] = None, q_rope=None) -> torch.Tensor:
         """q [T,Hq,D] (rows may be strided); k/v [T,Hkv,D] are only read when no cache
-        is attached.  Returns [T, Hq*D]."""
+        is attached.  ``q_rope`` (prefill steps only): q holds the raw projection, see
+        ``ops.flash_attention_prefill``.  Returns [T, Hq*D]."""
         ctx = get_context()
         T = q.shape[0]
+        assert q_rope is None or self.fuses_q_rope(ctx, q)
         if ctx.is_prefill and ctx.num_decode_seqs:
             return self._mixed(q, ctx)
         if ctx.is_prefill:
@@ -88,10 +102,10 @@ class Attention(nn.Module):
                 o = ops.paged_attention_prefill(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q,
                                                 ctx.cu_seqlens_k, ctx.block_tables, self.scale,
                                                 ctx.max_seqlen_q, max_seqlen_k=ctx.max_seqlen_k,
-                                                total_k=ctx.total_k_tokens)
+                                                total_k=ctx.total_k_tokens, q_rope=q_rope)
             else:
                 o = ops.flash_attention_prefill(q, k, v, ctx.cu_seqlens_q, self.scale,
-                                                ctx.max_seqlen_q)
+                                                ctx.max_seqlen_q, q_rope=q_rope)
         else:
             if self.k_cache is None:
                 raise RuntimeError("decode needs an allocated KV cache")

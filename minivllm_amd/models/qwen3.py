@@ -71,13 +71,17 @@ class Qwen3Attention(nn.Module):
         the result into a norm with a residual, which may take over the TP all-reduce
         (``RowParallelLinear.forward``)."""
         ctx = get_context()
+        cos_sin = self._rope[0].cos_sin_cache
+        q_weight = self.q_norm.weight if self.use_qk_norm else None
+        # pure prefill steps on the GPU: the store kernel handles K and V only and the
+        # attention kernel norms and rotates its Q rows while loading them
+        fuse = self.attn.fuses_q_rope(ctx, qkv)
         q, k, v = ops.qk_norm_rope_store(
-            qkv, positions, self._rope[0].cos_sin_cache,
-            self.q_norm.weight if self.use_qk_norm else None,
+            qkv, positions, cos_sin, q_weight,
             self.k_norm.weight if self.use_qk_norm else None,
             self.eps, self.num_heads, self.num_kv_heads, self.head_dim,
-            self.attn.k_cache, self.attn.v_cache, ctx.slot_mapping)
-        o = self.attn(q, k, v)
+            self.attn.k_cache, self.attn.v_cache, ctx.slot_mapping, skip_q=fuse)
+        o = self.attn(q, k, v, q_rope=(positions, cos_sin, q_weight, self.eps) if fuse else None)
         return self.o_proj(o, defer_reduce=defer_reduce)
 
 

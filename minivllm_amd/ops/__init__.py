@@ -43,10 +43,12 @@ def silu_and_mul(x):
 
 
 def qk_norm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, num_heads, num_kv_heads,
-                       head_dim, k_cache, v_cache, slot_mapping):
+                       head_dim, k_cache, v_cache, slot_mapping, skip_q=False):
+    """``skip_q``: leave the Q rows as projected; the prefill attention call that follows is
+    then given ``q_rope`` and transforms them while loading (one pass over Q less)."""
     f = _hip().qk_norm_rope_store if _on_gpu(qkv) else torch_ref.qk_norm_rope_store
     return f(qkv, positions, cos_sin, q_weight, k_weight, eps, num_heads, num_kv_heads, head_dim,
-             k_cache, v_cache, slot_mapping)
+             k_cache, v_cache, slot_mapping, skip_q)
 
 
 def store_kvcache(key, value, k_cache, v_cache, slot_mapping):
@@ -54,10 +56,12 @@ def store_kvcache(key, value, k_cache, v_cache, slot_mapping):
     return f(key, value, k_cache, v_cache, slot_mapping)
 
 
-def flash_attention_prefill(q, k, v, cu_seqlens, scale, max_seqlen=None):
+def flash_attention_prefill(q, k, v, cu_seqlens, scale, max_seqlen=None, q_rope=None):
+    """``q_rope`` = (positions, cos_sin, q_norm weight or None, eps): q holds raw projections and
+    the kernel applies q-norm + RoPE to them (see ``qk_norm_rope_store(skip_q=True)``)."""
     if _on_gpu(q):
-        return _hip().flash_attention_prefill(q, k, v, cu_seqlens, scale, max_seqlen)
-    return torch_ref.flash_attention_prefill(q, k, v, cu_seqlens, scale)
+        return _hip().flash_attention_prefill(q, k, v, cu_seqlens, scale, max_seqlen, q_rope=q_rope)
+    return torch_ref.flash_attention_prefill(torch_ref.apply_q_rope(q, q_rope), k, v, cu_seqlens, scale)
 
 
 def _into(out, res):
@@ -68,16 +72,19 @@ def _into(out, res):
 
 
 def paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k, block_tables, scale,
-                            max_seqlen_q=None, out=None, max_seqlen_k=None, total_k=None):
+                            max_seqlen_q=None, out=None, max_seqlen_k=None, total_k=None,
+                            q_rope=None):
     """``out``: optional [T, Hq, D] destination (a view into a larger buffer is fine).
     ``max_seqlen_k`` / ``total_k`` (longest context, sum of contexts) spare an fp8 cache's
     widening pass a device synchronisation and an oversized scratch buffer."""
     if _on_gpu(q):
         return _hip().paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k,
                                               block_tables, scale, max_seqlen_q, out=out,
-                                              max_seqlen_k=max_seqlen_k, total_k=total_k)
-    return _into(out, torch_ref.paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q,
-                                                        cu_seqlens_k, block_tables, scale))
+                                              max_seqlen_k=max_seqlen_k, total_k=total_k,
+                                              q_rope=q_rope)
+    return _into(out, torch_ref.paged_attention_prefill(torch_ref.apply_q_rope(q, q_rope), k_cache,
+                                                        v_cache, cu_seqlens_q, cu_seqlens_k,
+                                                        block_tables, scale))
 
 
 def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scale,

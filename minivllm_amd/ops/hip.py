@@ -42,7 +42,7 @@ _silu = _sig("mvl_silu_and_mul", _c_void, _c_void, _c_long, _c_int, _c_long, _c_
              _c_void)
 _rope = _sig("mvl_qk_norm_rope_store", _c_void, _c_long, _c_void, _c_void, _c_void, _c_void,
              _c_float, _c_long, _c_int, _c_int, _c_int, _c_void, _c_void, _c_long, _c_long,
-             _c_long, _c_int, _c_void, _c_int, _c_int, _c_void)
+             _c_long, _c_int, _c_void, _c_int, _c_int, _c_int, _c_void)
 _gather_widen = _sig("mvl_kv_gather_widen", _c_void, _c_void, _c_long, _c_long, _c_long, _c_int,
                      _c_void, _c_int, _c_void, _c_void, _c_void, _c_int, _c_int, _c_int, _c_int,
                      _c_int, _c_void)
@@ -57,7 +57,7 @@ _decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void,
 _prefill = _sig("mvl_flash_attention_prefill", _c_void, _c_long, _c_long, _c_void, _c_void,
                 _c_long, _c_long, _c_long, _c_void, _c_long, _c_long, _c_void, _c_void, _c_void,
                 _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                _c_void)
+                _c_void, _c_void, _c_void, _c_float, _c_void)
 
 _naive = _sig("mvl_naive_attention", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long, _c_long,
               _c_void, _c_long, _c_long, _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -167,8 +167,10 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
                        q_weight: Optional[torch.Tensor], k_weight: Optional[torch.Tensor],
                        eps: float, num_heads: int, num_kv_heads: int, head_dim: int,
                        k_cache: Optional[torch.Tensor], v_cache: Optional[torch.Tensor],
-                       slot_mapping: Optional[torch.Tensor]):
-    """Works in place on ``qkv`` [T, (Hq+2Hkv)*D]; returns (q, k, v) views of it."""
+                       slot_mapping: Optional[torch.Tensor], skip_q: bool = False):
+    """Works in place on ``qkv`` [T, (Hq+2Hkv)*D]; returns (q, k, v) views of it.  ``skip_q``:
+    the Q rows are left as projected (the prefill attention kernel transforms them itself when
+    it is handed ``q_rope``)."""
     assert qkv.dim() == 2 and qkv.stride(1) == 1
     T = qkv.shape[0]
     qs, ks = num_heads * head_dim, num_kv_heads * head_dim
@@ -194,7 +196,7 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
                  k_cache.data_ptr() if have_cache else None,
                  v_cache.data_ptr() if have_cache else None, sb, st, sh, bs,
                  slot_mapping.data_ptr() if have_cache else None, _dt(qkv),
-                 _kv_fp8(k_cache) if have_cache else 0, _stream()),
+                 _kv_fp8(k_cache) if have_cache else 0, int(skip_q), _stream()),
            "qk_norm_rope_store")
     q = qkv[:, :qs].view(T, num_heads, head_dim)
     k = qkv[:, qs:qs + ks].view(T, num_kv_heads, head_dim)
@@ -224,9 +226,25 @@ def _q_strides(q: torch.Tensor):
     return q.stride(0), q.stride(1)
 
 
+def _q_rope_args(q: torch.Tensor, q_rope):
+    """``q_rope`` = (positions [T], cos_sin fp32 [max_pos, D], q_norm weight or None, eps): the
+    raw-Q transform the prefill kernel applies while loading its Q rows -> kernel arguments."""
+    if q_rope is None:
+        return None, None, None, 0.0
+    positions, cos_sin, q_weight, eps = q_rope
+    if cos_sin.dtype != torch.float32 or cos_sin.shape[-1] != q.shape[-1] or not cos_sin.is_contiguous():
+        raise TypeError("cos/sin table must be contiguous fp32 [positions, head_dim]")
+    positions = _i32(positions)
+    assert positions.numel() >= q.shape[0] and positions.is_contiguous()
+    if q_weight is not None:
+        assert q_weight.dtype == q.dtype and q_weight.numel() == q.shape[-1] and q_weight.is_contiguous()
+    # keep the converted positions alive until the launch has been issued
+    return positions, cos_sin.data_ptr(), q_weight.data_ptr() if q_weight is not None else None, float(eps)
+
+
 def flash_attention_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
                             cu_seqlens: torch.Tensor, scale: float,
-                            max_seqlen: Optional[int] = None) -> torch.Tensor:
+                            max_seqlen: Optional[int] = None, q_rope=None) -> torch.Tensor:
     T, hq, d = q.shape
     hkv = k.shape[1]
     cu = _i32(cu_seqlens)
@@ -236,9 +254,11 @@ def flash_attention_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     ks_t, ks_h = _q_strides(k)
     assert _q_strides(v) == (ks_t, ks_h), "k and v must share strides"
     out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    pos, cs, qw, eps = _q_rope_args(q, q_rope)
     _check(_prefill(q.data_ptr(), qs_t, qs_h, k.data_ptr(), v.data_ptr(), ks_t, ks_h, 0,
                     out.data_ptr(), out.stride(0), out.stride(1), cu.data_ptr(), cu.data_ptr(),
                     None, 0, 1, scale, cu.numel() - 1, hq, hkv, d, max_seqlen, 0, _dt(q),
+                    pos.data_ptr() if pos is not None else None, cs, qw, eps,
                     _stream()), "flash_attention_prefill")
     return out
 
@@ -270,7 +290,7 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
                             max_seqlen_q: Optional[int] = None,
                             out: Optional[torch.Tensor] = None,
                             max_seqlen_k: Optional[int] = None,
-                            total_k: Optional[int] = None) -> torch.Tensor:
+                            total_k: Optional[int] = None, q_rope=None) -> torch.Tensor:
     T, hq, d = q.shape
     hkv = k_cache.shape[2]
     cq, ck, bt = _i32(cu_seqlens_q), _i32(cu_seqlens_k), _i32(block_tables)
@@ -278,7 +298,7 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
         max_seqlen_q = int((cq[1:] - cq[:-1]).max().item())
     if _kv_fp8(k_cache):
         return _prefill_over_fp8_cache(q, k_cache, v_cache, cq, ck, bt, scale, max_seqlen_q,
-                                       max_seqlen_k, total_k, out)
+                                       max_seqlen_k, total_k, out, q_rope)
     qs_t, qs_h = _q_strides(q)
     sb, st, sh = _cache_strides(k_cache)
     assert _cache_strides(v_cache) == (sb, st, sh)
@@ -286,15 +306,17 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
     if out is None:
         out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
     assert out.shape == (T, hq, d) and out.stride(2) == 1 and out.dtype == q.dtype
+    pos, cs, qw, eps = _q_rope_args(q, q_rope)
     _check(_prefill(q.data_ptr(), qs_t, qs_h, k_cache.data_ptr(), v_cache.data_ptr(), st, sh, sb,
                     out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
                     bt.data_ptr(), bt.stride(0), k_cache.shape[1], scale, cq.numel() - 1, hq, hkv,
-                    d, max_seqlen_q, 1, _dt(q), _stream()), "paged_attention_prefill")
+                    d, max_seqlen_q, 1, _dt(q), pos.data_ptr() if pos is not None else None, cs, qw,
+                    eps, _stream()), "paged_attention_prefill")
     return out
 
 
 def _prefill_over_fp8_cache(q, k_cache, v_cache, cq, ck, bt, scale, max_seqlen_q, max_seqlen_k,
-                            total_k, out):
+                            total_k, out, q_rope=None):
     """fp8 cache: widen the contexts of the step's sequences into packed 16-bit K/V
     (``kv_gather_widen``), then run the packed flash kernel with separate q / k lengths."""
     T, hq, d = q.shape
@@ -314,9 +336,11 @@ def _prefill_over_fp8_cache(q, k_cache, v_cache, cq, ck, bt, scale, max_seqlen_q
     qs_t, qs_h = _q_strides(q)
     if out is None:
         out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
+    pos, cs, qw, eps = _q_rope_args(q, q_rope)
     _check(_prefill(q.data_ptr(), qs_t, qs_h, k.data_ptr(), v.data_ptr(), k.stride(0), k.stride(1),
                     0, out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
-                    None, 0, 1, scale, B, hq, hkv, d, max_seqlen_q, 0, _dt(q), _stream()),
+                    None, 0, 1, scale, B, hq, hkv, d, max_seqlen_q, 0, _dt(q),
+                    pos.data_ptr() if pos is not None else None, cs, qw, eps, _stream()),
            "flash_attention_prefill (fp8 cache)")
     return out
 

@@ -108,8 +108,9 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
                        q_weight: Optional[torch.Tensor], k_weight: Optional[torch.Tensor],
                        eps: float, num_heads: int, num_kv_heads: int, head_dim: int,
                        k_cache: Optional[torch.Tensor], v_cache: Optional[torch.Tensor],
-                       slot_mapping: Optional[torch.Tensor]):
-    """Fused per-head RMSNorm(q,k) + RoPE(q,k) + KV-cache store.
+                       slot_mapping: Optional[torch.Tensor], skip_q: bool = False):
+    """Fused per-head RMSNorm(q,k) + RoPE(q,k) + KV-cache store.  ``skip_q``: q is returned as
+    projected (``apply_q_rope`` is then the consumer's job).
 
     qkv: [T, (Hq + 2 Hkv) * D].  Returns (q [T,Hq,D], k [T,Hkv,D], v [T,Hkv,D]) in
     the input dtype; k/v are also scattered to the cache when one is given.
@@ -117,7 +118,8 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
     T = qkv.shape[0]
     qs, ks = num_heads * head_dim, num_kv_heads * head_dim
     q, k, v = qkv.split([qs, ks, ks], dim=-1)
-    q = q.reshape(T, num_heads, head_dim).float()
+    q_raw = q.reshape(T, num_heads, head_dim)
+    q = q_raw.float()
     k = k.reshape(T, num_kv_heads, head_dim).float()
     v = v.reshape(T, num_kv_heads, head_dim)
     if q_weight is not None:
@@ -131,7 +133,21 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
     k = apply_rope(k, cos, sin).to(qkv.dtype)
     if k_cache is not None and slot_mapping is not None:
         store_kvcache(k, v, k_cache, v_cache, slot_mapping)
-    return q, k, v.contiguous()
+    return (q_raw if skip_q else q), k, v.contiguous()
+
+
+def apply_q_rope(q: torch.Tensor, q_rope) -> torch.Tensor:
+    """The transform a prefill attention kernel applies to raw Q rows when it is handed
+    ``q_rope`` = (positions, cos_sin, q_norm weight or None, eps): per-head RMSNorm, then RoPE."""
+    if q_rope is None:
+        return q
+    positions, cos_sin, q_weight, eps = q_rope
+    x = q.float()
+    if q_weight is not None:
+        x = x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps) * q_weight.float()
+    cs = cos_sin[positions[:q.shape[0]].long()].float()
+    cos, sin = cs.chunk(2, dim=-1)
+    return apply_rope(x, cos, sin).to(q.dtype)
 
 
 # ------------------------------------------------------------- attention

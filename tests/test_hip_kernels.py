@@ -334,6 +334,51 @@ def test_paged_prefill_with_prefix(hip, dtype, bs, hq, hkv, d):
     close(got, want, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (16, 8, 64), (8, 1, 128)])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_prefill_transforms_raw_q_rows(hip, dtype, hq, hkv, d, with_norm):
+    """skip_q + q_rope: the store kernel leaves the Q columns of the fused projection as they
+    are and the prefill kernel applies q-norm + RoPE while loading them.  Checked against the
+    unfused pair of launches (same arithmetic, so nearly the same bits) and the fp32 oracle;
+    packed and paged with cached prefixes."""
+    torch.manual_seed(50 + d)
+    q_lens = [1, 60, 64, 129, 300, 17]
+    prefix = [0, 0, 256, 0, 512, 256]
+    k_lens = [a + b for a, b in zip(q_lens, prefix)]
+    T, bs = sum(q_lens), 256
+    eps, scale = 1e-6, 1.0 / math.sqrt(d)
+    qkv = torch.randn(T, (hq + 2 * hkv) * d, device=DEV, dtype=dtype)
+    pos = torch.cat([torch.arange(p, p + n) for p, n in zip(prefix, q_lens)]).to(DEV, torch.int32)
+    cs = ref.build_cos_sin_cache(d, 1024, 10000.0, DEV)
+    qw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype) if with_norm else None
+    kw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype) if with_norm else None
+    cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    rope = (pos, cs, qw, eps)
+
+    a = qkv.clone()
+    q_a, k_a, v_a = hip.qk_norm_rope_store(a, pos, cs, qw, kw, eps, hq, hkv, d, None, None, None)
+    b = qkv.clone()
+    q_b, k_b, v_b = hip.qk_norm_rope_store(b, pos, cs, qw, kw, eps, hq, hkv, d, None, None, None,
+                                           skip_q=True)
+    assert torch.equal(q_b, qkv[:, :hq * d].view(T, hq, d))        # untouched
+    assert torch.equal(k_b, k_a) and torch.equal(v_b, v_a)
+    close(ref.apply_q_rope(q_b, rope), q_a, dtype, 2)
+    unfused = hip.flash_attention_prefill(q_a, k_a, v_a, cu, scale)
+    fused = hip.flash_attention_prefill(q_b, k_b, v_b, cu, scale, q_rope=rope)
+    close(fused, unfused, dtype)
+    close(fused, ref.flash_attention_prefill(q_a, k_a, v_a, cu, scale), dtype)
+
+    kk = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    vv = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(kk, vv, k_lens, bs, hkv, d, dtype)
+    ck = torch.tensor([0] + list(torch.tensor(k_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    unfused = hip.paged_attention_prefill(q_a, kc, vc, cu, ck, tables, scale)
+    fused = hip.paged_attention_prefill(q_b, kc, vc, cu, ck, tables, scale, q_rope=rope)
+    close(fused, unfused, dtype)
+    close(fused, ref.paged_attention_prefill(q_a, kc, vc, cu, ck, tables, scale), dtype)
+
+
 @pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (16, 8, 128), (8, 1, 128), (16, 8, 64)])
 def test_prefill_many_uneven_sequences(hip, hq, hkv, d):
     """Several thousand workgroups over 44 sequences of uneven length (Q tiles without rows,

@@ -46,6 +46,7 @@ int main(int argc, char** argv) {
     a.cu_q = dcu; a.cu_k = dcu; a.block_tables = nullptr; a.bt_stride = 0; a.bs_log2 = 0;
     a.scale_log2 = kLog2e / sqrtf((float)D);
     a.B = B; a.Hq = Hq; a.Hkv = Hkv;
+    a.positions = nullptr; a.cos_sin = nullptr; a.q_w = nullptr; a.eps = 0.f;
     a.n_qtiles = (S + kBM - 1) / kBM;
     a.total_wg = B * Hq * a.n_qtiles;
     CK(hipMalloc(&probe, (size_t)a.total_wg * 8 * 8));
