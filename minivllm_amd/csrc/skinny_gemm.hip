@@ -13,6 +13,10 @@
 //    instruction; the loop is unrolled 8 deep so each row is read in 512-byte bursts;
 //  * x (at most 16 rows, L2 resident) is the A operand, loaded the same way; rows >= M are
 //    clamped duplicates whose results are dropped;
+//  * projections with few column tiles (N = 4096: one workgroup per CU) can also split K over
+//    workgroups (grid.y): each writes its fp32 partial tile into a slab [split][M][N] that the
+//    consumer sums - the residual-add + RMSNorm kernel that follows an o / down projection
+//    does that in passing, so the split costs no launch;
 //  * epilogues: plain (+ optional bias), or SwiGLU: the tile computes the gate and the up
 //    projection of the same 16 columns (rows n and I + n of the fused weight) with one shared
 //    x fragment and stores silu(gate) * up, which removes the activation kernel and the
@@ -26,11 +30,13 @@ namespace {
 
 constexpr int kUnroll = 8;
 
+// ws != nullptr (EPI 0 only): blockIdx.y selects the K range [y k_len, (y + 1) k_len) and the
+// fp32 sums go to ws[y][M][16 gridDim.x] instead of out.
 template <int CODE, int EPI, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
         const uint16_t* __restrict__ x, long x_stride, const uint16_t* __restrict__ w,
         const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, long o_stride, int M,
-        int K, int up_row_offset) {
+        int K, int up_row_offset, float* __restrict__ ws, int k_len) {
     using DT = DType<CODE>;
     using vec8 = typename DT::vec8;
     constexpr int NB = EPI == 1 ? 2 : 1;
@@ -40,8 +46,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c16 = lane & 15, q4 = lane >> 4;
     const int n0 = blockIdx.x * 16;
-    const int kslice = K / WAVES;
-    const long koff = (long)wv * kslice + 8 * q4;
+    const int kslice = k_len / WAVES;
+    const long koff = (long)blockIdx.y * k_len + (long)wv * kslice + 8 * q4;
     const uint16_t* wp0 = w + (long)(n0 + c16) * K + koff;
     const uint16_t* wp1 = w + (long)(up_row_offset + n0 + c16) * K + koff;
     const uint16_t* xp = x + (long)min(c16, M - 1) * x_stride + koff;
@@ -96,6 +102,10 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
 #pragma unroll
                 for (int ww = 0; ww < WAVES; ++ww) s[b] += red[ww][b][m][n];
             }
+            if (EPI == 0 && ws != nullptr) {
+                ws[((long)blockIdx.y * M + m) * (16L * gridDim.x) + n0 + n] = s[0];
+                return;
+            }
             float r;
             if (EPI == 1) {
                 if (bias != nullptr) {
@@ -115,20 +125,22 @@ int g_force_waves = 0;        // tuning aid (mvl_skinny_gemm_force_waves): 0 = a
 
 template <int CODE, int EPI>
 int launch(const void* x, long xs, const void* w, const void* bias, void* out, long os, int M,
-           int N_out, int K, int up_off, hipStream_t st) {
-    const int tiles = N_out / 16;
+           int N_out, int K, int up_off, hipStream_t st, float* ws = nullptr, int splits = 1) {
     auto X = (const uint16_t*)x; auto W = (const uint16_t*)w; auto B = (const uint16_t*)bias;
     auto O = (uint16_t*)out;
+    const dim3 tiles(N_out / 16, splits);
+    const int KT = K;                            // row pitch of W and length of x rows
+    K /= splits;                                 // what one workgroup covers
     // 8 waves split K (4 when K is not a multiple of 256).  Measured on Qwen3-8B shapes with
     // cold weights: 8 waves beat 16 everywhere (o-projection 8.3 vs 9.1 us, fused SwiGLU 35.9
     // vs 40.5 us) - fewer, longer streams per wave and half the LDS reduction.
     const int waves = g_force_waves ? g_force_waves : (K % 256 == 0 ? 8 : 4);
     if (waves == 16 && K % 512 == 0)
-        skinny_gemm_kernel<CODE, EPI, 16><<<tiles, 16 * 64, 0, st>>>(X, xs, W, B, O, os, M, K, up_off);
+        skinny_gemm_kernel<CODE, EPI, 16><<<tiles, 16 * 64, 0, st>>>(X, xs, W, B, O, os, M, KT, up_off, ws, K);
     else if (waves == 8 && K % 256 == 0)
-        skinny_gemm_kernel<CODE, EPI, 8><<<tiles, 8 * 64, 0, st>>>(X, xs, W, B, O, os, M, K, up_off);
+        skinny_gemm_kernel<CODE, EPI, 8><<<tiles, 8 * 64, 0, st>>>(X, xs, W, B, O, os, M, KT, up_off, ws, K);
     else if (K % 128 == 0)
-        skinny_gemm_kernel<CODE, EPI, 4><<<tiles, 4 * 64, 0, st>>>(X, xs, W, B, O, os, M, K, up_off);
+        skinny_gemm_kernel<CODE, EPI, 4><<<tiles, 4 * 64, 0, st>>>(X, xs, W, B, O, os, M, KT, up_off, ws, K);
     else
         return -1;
     return MVL_CHECK_LAUNCH();
@@ -155,4 +167,17 @@ extern "C" int mvl_skinny_gemm(const void* x, long x_stride, const void* w, cons
     const int inter = N / 2;
     return dtype == 0 ? launch<0, 1>(x, x_stride, w, bias, out, o_stride, M, inter, K, inter, st)
                       : launch<1, 1>(x, x_stride, w, bias, out, o_stride, M, inter, K, inter, st);
+}
+
+// K split over ``splits`` workgroups per column tile: ws[splits][M][N] fp32 receives the
+// partial products (no bias); K / splits must be a multiple of 128.
+extern "C" int mvl_skinny_gemm_splitk(const void* x, long x_stride, const void* w, void* ws, int M,
+                                      int N, int K, int splits, int dtype, void* stream) {
+    if (M == 0) return 0;
+    if (M > 16 || N % 16 != 0 || splits < 1 || splits > 16 || ws == nullptr) return -1;
+    if (K % splits != 0 || (K / splits) % 128 != 0) return -1;
+    auto st = (hipStream_t)stream;
+    return dtype == 0
+        ? launch<0, 0>(x, x_stride, w, nullptr, nullptr, 0, M, N, K, 0, st, (float*)ws, splits)
+        : launch<1, 0>(x, x_stride, w, nullptr, nullptr, 0, M, N, K, 0, st, (float*)ws, splits);
 }

@@ -211,6 +211,10 @@ class ModelRunner:
         rows = [b for b in hip.MID_ROW_BUCKETS if b // 2 < self.max_bs]
         for name, (ws, swiglu) in roles.items():
             self.decode_gemm_choices[name] = hip.tune_skinny_gemm(ws, swiglu)
+            if name in ("o", "down") and self.world_size == 1:
+                # few column tiles: K may also be split over workgroups, the norm behind the
+                # projection sums the slices (rows: library us, kernel us, split; 0 = library)
+                self.decode_gemm_choices[name + "+norm"] = hip.tune_skinny_to_norm(ws)
             if self.max_bs > hip.SKINNY_MAX_ROWS:
                 # o / down feed a residual add + norm: on one rank their K-slice sum is folded
                 # into that norm, so they are tuned together with it
@@ -911,9 +915,26 @@ class ModelRunner:
             return tokens
         dev = logits.device
         ridx = torch.as_tensor(rows, device=dev)
+        if self.on_gpu:
+            # one kernel, no sort (rejection sampling with a rising pivot, csrc/sampler.hip)
+            from minivllm_amd.ops import hip
+            rows32 = ridx.to(torch.int32)
+            if self.world_size > 1 or pg.collectives_active():
+                lg = pg.tp_all_gather(logits[:B].index_select(0, ridx), dim=-1).contiguous()
+                logit_rows = torch.arange(rows.size, dtype=torch.int32, device=dev)
+            else:
+                lg, logit_rows = logits, rows32
+            if tokens is None:                   # workers only take part in the gather
+                return None
+            assert tokens.dtype == torch.int32
+            hip.sample_filtered(
+                lg, logit_rows, rows32,
+                torch.as_tensor(a["temperatures"][:B].astype(np.float32), device=dev),
+                torch.as_tensor(a["top_k"][:B].astype(np.int32), device=dev),
+                torch.as_tensor(a["top_p"][:B].astype(np.float32), device=dev),
+                self.cfg.seed, b.step, tokens, vocab=self.cfg.model.vocab_size)
+            return tokens
         lg = logits[:B].index_select(0, ridx)
-        if self.on_gpu and (self.world_size > 1 or pg.collectives_active()):
-            lg = pg.tp_all_gather(lg, dim=-1)                     # shards in vocabulary order
         lg = lg[:, :self.cfg.model.vocab_size].float()
         lg = lg / torch.as_tensor(a["temperatures"][rows], device=dev)[:, None]
         vals, order = lg.sort(dim=-1, descending=True)
@@ -946,7 +967,24 @@ class ModelRunner:
                       flush=True)
             self.enforce_eager = True
             return
-        self.capture_graphs()
+        try:
+            self.capture_graphs()
+        except Exception as e:                   # noqa: BLE001
+            # One rank: a capture failure is a bug and stays loud.  Several ranks: a collective
+            # library that cannot be captured on this machine must not cost the run - replayed
+            # and eager steps issue the same collectives in the same order, so ranks that did
+            # capture stay compatible with ranks that did not.
+            if self.world_size == 1:
+                raise
+            print(f"[runner] rank {self.rank}: hipGraph capture failed ({e!r}); steps run eagerly",
+                  flush=True)
+            self.graphs.clear()
+            self.prefill_graphs.clear()
+            self.enforce_eager = True
+            try:
+                torch.cuda.synchronize()
+            except Exception:                    # noqa: BLE001
+                pass
 
     @torch.inference_mode()
     def capture_graphs(self) -> None:

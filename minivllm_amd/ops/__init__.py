@@ -106,7 +106,10 @@ def linear(x, weight, bias=None, to_norm=False):
     if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 256:
         h = _hip()
         if x.shape[0] <= 16:
-            if h.skinny_gemm_pays(x, weight):
+            sp = h.skinny_gemm_splits(x, weight) if to_norm else None
+            if sp:
+                return h.skinny_linear(x, weight, bias, splits=sp, defer=True)
+            if sp is None and h.skinny_gemm_pays(x, weight):
                 return h.skinny_linear(x, weight, bias)
         else:
             c = h.mid_gemm_choice(x, weight, to_norm=to_norm)

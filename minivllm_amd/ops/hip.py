@@ -50,6 +50,9 @@ _store = _sig("mvl_store_kvcache", _c_void, _c_void, _c_long, _c_long, _c_void, 
               _c_long, _c_long, _c_int, _c_void, _c_long, _c_int, _c_int, _c_void)
 _sample = _sig("mvl_sample", _c_void, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void, _c_u64,
                _c_void, _c_void, _c_void, _c_int, _c_int, _c_void, _c_void, _c_void)
+_sample_filtered = _sig("mvl_sample_filtered", _c_void, _c_long, _c_int, _c_int, _c_void, _c_void,
+                        _c_void, _c_void, _c_void, _c_u64, _c_void, _c_void, _c_void, _c_int,
+                        _c_void)
 _decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
                _c_long, _c_long, _c_void, _c_int, _c_void, _c_void, _c_long, _c_long, _c_void,
                _c_void, _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -66,6 +69,8 @@ _naive = _sig("mvl_naive_attention", _c_void, _c_long, _c_long, _c_void, _c_void
 _skinny = _sig("mvl_skinny_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_int,
                _c_int, _c_int, _c_int, _c_int, _c_void)
 
+_skinny_splitk = _sig("mvl_skinny_gemm_splitk", _c_void, _c_long, _c_void, _c_void, _c_int, _c_int,
+                      _c_int, _c_int, _c_int, _c_void)
 _skinny_norm = _sig("mvl_skinny_norm_gemm", _c_void, _c_long, _c_void, _c_long, _c_void, _c_long,
                     _c_float, _c_void, _c_void, _c_void, _c_long, _c_int, _c_int, _c_int,
                     _c_int, _c_int, _c_void)
@@ -460,6 +465,54 @@ def skinny_gemm_pays(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False
     return swiglu or (n <= 4096 and k <= 4096)
 
 
+def skinny_gemm_splits(x: torch.Tensor, weight: torch.Tensor) -> int:
+    """For a projection whose output goes straight into residual add + RMSNorm: the K split
+    (over workgroups) that was measured fastest together with that norm, 0 = library GEMM,
+    None = never measured (the caller falls back to ``skinny_gemm_pays``)."""
+    if x.dim() != 2 or x.shape[0] > SKINNY_PAYS_ROWS or not skinny_gemm_ok(x, weight):
+        return None
+    n, k = weight.shape
+    return _SKINNY_CHOICE.get((_row_bucket(x.shape[0]), n, k, "norm"))
+
+
+def tune_skinny_to_norm(weights, margin: float = 0.97) -> dict:
+    """``tune_skinny_gemm`` for a projection followed by residual add + RMSNorm (o, down): the
+    library GEMM + norm kernel against the weight-streaming kernel with K split 1..4 ways over
+    workgroups, whose slices the norm kernel sums.  Records the best split (0 = library) under
+    the ``"norm"`` key; returns {rows: (library us, best kernel us, split)}."""
+    import torch.nn.functional as F
+    weights = list(weights)
+    n, k = weights[0].shape
+    dtype, dev = weights[0].dtype, weights[0].device
+    out = {}
+    if not skinny_gemm_ok(torch.zeros(1, k, dtype=dtype, device=dev), weights[0]) \
+            or n * k * 2 < (1 << 20) or n > 32768:
+        return out
+    reps = max(1, min(8, -(-(640 << 20) // (n * k * 2 * len(weights)))))
+    gamma = torch.ones(n, dtype=dtype, device=dev)
+    for m in _SKINNY_ROW_BUCKETS:
+        x = torch.randn(m, k, dtype=dtype, device=dev)
+        resid = torch.zeros(m, n, dtype=dtype, device=dev)
+        t_lib = _graph_time_ms(lambda xx, w: add_rms_norm(F.linear(xx, w), resid, gamma, 1e-6),
+                               x, weights, reps)
+        best, t_best = 0, t_lib * margin
+        for sp in (1, 2, 3, 4):
+            if not skinny_splits_ok(k, sp):
+                continue
+
+            def ker(xx, w):
+                y = skinny_linear(xx, w, splits=sp, defer=True)
+                if isinstance(y, SplitKPartials):
+                    return y.add_rms_norm(resid, gamma, 1e-6)
+                return add_rms_norm(y, resid, gamma, 1e-6)
+            t = _graph_time_ms(ker, x, weights, reps)
+            if t < t_best:
+                best, t_best = sp, t
+        _SKINNY_CHOICE[(m, n, k, "norm")] = best
+        out[m] = (round(t_lib * 1e3, 1), round(t_best * 1e3, 1) if best else None, best)
+    return out
+
+
 def tune_skinny_gemm(weights, swiglu: bool = False, margin: float = 0.97) -> dict:
     """Time the weight-streaming kernel against the library GEMM (+ activation kernel when
     ``swiglu``) for one projection and record the winner per row bucket.  ``weights`` are the
@@ -513,12 +566,24 @@ def tune_skinny_gemm(weights, swiglu: bool = False, margin: float = 0.97) -> dic
     return out
 
 
+def skinny_splits_ok(k: int, splits: int) -> bool:
+    return splits >= 1 and k % splits == 0 and (k // splits) % 128 == 0
+
+
 def skinny_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-                  swiglu: bool = False) -> torch.Tensor:
+                  swiglu: bool = False, splits: int = 1, defer: bool = False):
     """``x @ weight.T (+ bias)`` for <= 16 rows; with ``swiglu`` the weight is the fused
-    [gate; up] matrix and the result is ``silu(gate) * up``."""
+    [gate; up] matrix and the result is ``silu(gate) * up``.  ``splits`` > 1 (plain epilogue
+    only) slices K over workgroups; the fp32 slices are summed by a second kernel or, with
+    ``defer``, handed over as ``SplitKPartials`` to the norm that consumes the projection."""
     M, K = x.shape
     N = weight.shape[0]
+    if splits > 1 and not swiglu and skinny_splits_ok(K, splits):
+        ws = torch.empty((splits, M, N), dtype=torch.float32, device=x.device)
+        _check(_skinny_splitk(x.data_ptr(), x.stride(0), weight.data_ptr(), ws.data_ptr(), M, N, K,
+                              splits, _dt(x), _stream()), "skinny_gemm_splitk")
+        part = SplitKPartials(ws, bias, x.dtype)
+        return part if defer else part.materialize()
     out = torch.empty((M, N // 2 if swiglu else N), dtype=x.dtype, device=x.device)
     _check(_skinny(x.data_ptr(), x.stride(0), weight.data_ptr(),
                    bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
@@ -766,6 +831,35 @@ def tune_mid_gemm(weights, swiglu: bool = False, rows=MID_ROW_BUCKETS,
 
 # -------------------------------------------------------------------- sampler
 _LOGIT_DT = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}
+
+
+def sample_filtered(logits: torch.Tensor, logit_rows: torch.Tensor, batch_rows: torch.Tensor,
+                    temperatures: torch.Tensor, top_k: torch.Tensor, top_p: torch.Tensor,
+                    seed: int, step, out: torch.Tensor, vocab: Optional[int] = None,
+                    rounds: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Draw the listed rows again from their top-k / top-p restricted distributions (no sort:
+    rejection sampling with a rising pivot, one workgroup per row, see csrc/sampler.hip) and
+    write the tokens into ``out[batch_rows]`` (int32).  ``logit_rows[i]`` is the row of
+    ``logits`` (full vocabulary, first ``vocab`` columns valid) that belongs to batch row
+    ``batch_rows[i]``; ``temperatures`` / ``top_k`` (int32, <= 0 = off) / ``top_p`` (fp32,
+    >= 1 = off) are indexed by batch row.  A row without a filter gets the token the plain
+    sampler draws for (seed, step, batch row)."""
+    assert logits.dim() == 2 and logits.stride(1) == 1 and out.dtype == torch.int32
+    n = logit_rows.numel()
+    assert batch_rows.numel() == n and logit_rows.dtype == batch_rows.dtype == torch.int32
+    assert top_k.dtype == torch.int32 and top_p.dtype == torch.float32
+    assert temperatures.dtype == torch.float32
+    need = int(batch_rows.max().item()) + 1 if n and not torch.cuda.is_current_stream_capturing() else 0
+    assert min(temperatures.numel(), top_k.numel(), top_p.numel(), out.numel()) >= need
+    if not torch.is_tensor(step):
+        step = torch.tensor([int(step) & 0x7fffffff], dtype=torch.int32, device=logits.device)
+    _check(_sample_filtered(logits.data_ptr(), logits.stride(0), vocab or logits.shape[1], n,
+                            logit_rows.data_ptr(), batch_rows.data_ptr(), temperatures.data_ptr(),
+                            top_k.data_ptr(), top_p.data_ptr(), seed & 0xFFFFFFFFFFFFFFFF,
+                            step.data_ptr(), out.data_ptr(),
+                            rounds.data_ptr() if rounds is not None else None,
+                            _LOGIT_DT[logits.dtype], _stream()), "sample_filtered")
+    return out
 
 
 def sample_local(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, step,

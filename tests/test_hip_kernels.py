@@ -175,6 +175,86 @@ def test_sampler_split_rows_equal_single_workgroup_rows(hip, dtype, V):
     assert one_i[0].item() == logits[0, :V - 3].float().argmax().item()
 
 
+def _kept_mask(logits, temps, top_k, top_p):
+    """The kept set of the filtered sampler, row by row, from a sort (fp64): token i stays iff
+    fewer than k tokens are strictly more likely and those hold less than p of the mass."""
+    sc = logits.double() / temps.double()[:, None]
+    prob = torch.softmax(sc, -1)
+    vals, order = sc.sort(-1, descending=True)
+    ps = prob.gather(1, order)
+    mass_before = ps.cumsum(-1) - ps
+    # tokens tied with their predecessor share its count / mass of strictly greater tokens
+    first = torch.ones_like(vals, dtype=torch.bool)
+    first[:, 1:] = vals[:, 1:] != vals[:, :-1]
+    pos = torch.arange(vals.shape[1], device=vals.device).expand_as(vals)
+    start = torch.where(first, pos, torch.zeros_like(pos)).cummax(-1).values
+    cnt_gt = start
+    mass_gt = mass_before.gather(1, start)
+    keep_sorted = ((top_k[:, None] <= 0) | (cnt_gt < top_k[:, None])) & (mass_gt < top_p[:, None].double())
+    keep = torch.zeros_like(keep_sorted)
+    keep.scatter_(1, order, keep_sorted)
+    return keep, prob
+
+
+@pytest.mark.parametrize("dtype,V", [(torch.bfloat16, 151936), (torch.float32, 40003), (torch.float16, 8192)])
+def test_filtered_sampler_membership_and_plain_rows(hip, dtype, V):
+    """Every drawn token lies in its row's kept set; rows without a filter and greedy rows get
+    exactly the plain sampler's token; k = 1 and a tiny p give a maximal token; same call, same
+    tokens.  Rows are listed in a shuffled order and read from a strided logits buffer."""
+    torch.manual_seed(31)
+    B = 24
+    logits = (torch.randn(B, V + 8, device=DEV) * 3).to(dtype)[:, :V]
+    temps = torch.full((B,), 0.9, device=DEV)
+    temps[5] = 0.0
+    top_k = torch.tensor([0, 1, 5, 50, 0, 3, 0, 1000] * 3, device=DEV, dtype=torch.int32)
+    top_p = torch.tensor([1.0, 1.0, 1.0, 0.9, 0.5, 0.9, 1e-6, 0.999] * 3, device=DEV)
+    plain = hip.sample(logits, temps, seed=77, step=5).to(torch.int32)
+    rows = torch.randperm(B, device=DEV).to(torch.int32)
+    out = torch.full((B,), -1, device=DEV, dtype=torch.int32)
+    rounds = torch.zeros(B, device=DEV, dtype=torch.int32)
+    hip.sample_filtered(logits, rows, rows, temps, top_k, top_p, 77, 5, out, rounds=rounds)
+    keep, _ = _kept_mask(logits.float(), temps.clamp_min(1e-3), top_k, top_p)
+    assert bool(keep.gather(1, out.long()[:, None]).all())
+    top = logits.float().max(-1).values
+    for r in range(B):
+        if top_k[r] <= 0 and top_p[r] >= 1.0 or temps[r] == 0:
+            assert out[r] == plain[r] and rounds[r] == 0
+        if top_k[r] == 1 or top_p[r] < 1e-5:
+            assert logits[r, out[r]].float() == top[r]        # (16-bit rows: the maximum may be tied)
+    assert int(rounds.max()) < 96
+    again = torch.full((B,), -1, device=DEV, dtype=torch.int32)
+    hip.sample_filtered(logits, rows, rows, temps, top_k, top_p, 77, 5, again)
+    assert torch.equal(out, again)
+    # a subset of the rows, read from a gathered copy: the other outputs stay untouched
+    sub = torch.tensor([7, 2, 19], device=DEV, dtype=torch.int32)
+    part = torch.full((B,), -1, device=DEV, dtype=torch.int32)
+    hip.sample_filtered(logits[sub.long()].contiguous(), torch.arange(3, device=DEV, dtype=torch.int32),
+                        sub, temps, top_k, top_p, 77, 5, part)
+    assert torch.equal(part[sub.long()], out[sub.long()]) and int((part >= 0).sum()) == 3
+
+
+@pytest.mark.parametrize("k,p", [(4, 1.0), (0, 0.8), (6, 0.7), (0, 0.999)])
+def test_filtered_sampler_distribution(hip, k, p):
+    """Frequencies over 30000 independent rows with the same logits match the renormalised
+    restricted distribution (flat-ish row: several rejection rounds are exercised)."""
+    torch.manual_seed(32)
+    V, n, T = 24, 30000, 1.1
+    base = torch.randn(V, device=DEV) * 1.5
+    logits = base.repeat(n, 1)
+    temps = torch.full((n,), T, device=DEV)
+    top_k = torch.full((n,), k, device=DEV, dtype=torch.int32)
+    top_p = torch.full((n,), p, device=DEV)
+    rows = torch.arange(n, device=DEV, dtype=torch.int32)
+    out = torch.empty(n, device=DEV, dtype=torch.int32)
+    hip.sample_filtered(logits, rows, rows, temps, top_k, top_p, 5, 9, out)
+    keep, prob = _kept_mask(base[None], temps[:1], top_k[:1], top_p[:1])
+    want = (prob * keep).float()[0]
+    want = want / want.sum()
+    freq = torch.bincount(out.long(), minlength=V).float() / n
+    assert (freq - want).abs().max().item() < 0.012
+    assert freq[~keep[0]].sum().item() == 0
+
+
 # ------------------------------------------------------------------- attention
 def _fill_paged(k, v, lens, bs, hkv, d, dtype, head_major=True, shuffle=True):
     """Scatter packed k/v [sum(lens), hkv, d] into a paged cache; returns caches + tables."""
@@ -471,6 +551,64 @@ def test_skinny_gemm(hip, dtype, M, N, K):
     want = x.float() @ w.float().T
     close(hip.skinny_linear(x, w), want, dtype, 4)
     close(hip.skinny_linear(x, w, b), want + b.float(), dtype, 4)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [1, 7, 16])
+@pytest.mark.parametrize("N,K,splits", [(4096, 4096, 2), (4096, 4096, 4), (4096, 12288, 3),
+                                        (4096, 12288, 4), (1024, 3072, 2), (5120, 5120, 2),
+                                        (6144, 4096, 2), (4096, 1536, 3)])
+def test_skinny_gemm_split_k(hip, dtype, M, N, K, splits):
+    """K split over workgroups: the fp32 slices summed by the reduce kernel and by the
+    residual-add + RMSNorm kernel, against the fp32 product; x is a strided view."""
+    torch.manual_seed(M + splits)
+    assert hip.skinny_splits_ok(K, splits)
+    x = torch.randn(M, K + 64, device=DEV, dtype=dtype)[:, :K]
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(dtype)
+    bias = torch.randn(N, device=DEV, dtype=dtype) if M == 7 else None
+    y = x.float() @ w.float().T + (bias.float() if bias is not None else 0)
+    assert _rel(hip.skinny_linear(x, w, bias, splits=splits), y) < 0.01
+    parts = hip.skinny_linear(x, w, bias, splits=splits, defer=True)
+    assert isinstance(parts, hip.SplitKPartials) and tuple(parts.ws.shape) == (splits, M, N)
+    # every slice is its own K range of the product
+    ks = K // splits
+    for i in range(splits):
+        part = x[:, i * ks:(i + 1) * ks].float() @ w[:, i * ks:(i + 1) * ks].float().T
+        assert _rel(parts.ws[i], part) < 1e-3
+    gamma = (1 + 0.1 * torch.randn(N, device=DEV)).to(dtype)
+    resid = torch.randn(M, N, device=DEV, dtype=dtype)
+    want_r = y + resid.float()
+    h, r = parts.add_rms_norm(resid, gamma, 1e-6)
+    assert r.data_ptr() == resid.data_ptr() and _rel(r, want_r) < 0.01
+    rf = r.float()
+    assert _rel(h, rf * torch.rsqrt(rf.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma.float()) < 0.01
+    # a split that does not divide K into multiples of 128 falls back to the unsplit kernel
+    t = hip.skinny_linear(x, w, bias, splits=7, defer=True)
+    assert torch.is_tensor(t) and _rel(t, y) < 0.01
+
+
+def test_ops_linear_to_norm_dispatch_few_rows(hip):
+    """<= 16 rows: ops.linear(to_norm=True) follows the split recorded by the start-up tuner
+    (0 = library, 1 = unsplit kernel, > 1 = partials), plain calls never see partials."""
+    from minivllm_amd import ops
+    M, N, K = 4, 4096, 4096
+    x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
+    y = x.float() @ w.float().T
+    saved = dict(hip._SKINNY_CHOICE)
+    try:
+        for choice, partials in ((None, False), (0, False), (1, False), (2, True), (4, True)):
+            hip._SKINNY_CHOICE.clear()
+            if choice is not None:
+                hip._SKINNY_CHOICE[(8, N, K, "norm")] = choice
+            out = ops.linear(x, w, to_norm=True)
+            assert isinstance(out, hip.SplitKPartials) == partials
+            assert torch.is_tensor(ops.linear(x, w))
+            got = out.materialize() if partials else out
+            assert _rel(got, y) < 0.01
+    finally:
+        hip._SKINNY_CHOICE.clear()
+        hip._SKINNY_CHOICE.update(saved)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
