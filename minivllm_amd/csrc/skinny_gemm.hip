@@ -32,7 +32,7 @@ constexpr int kUnroll = 8;
 
 // ws != nullptr (EPI 0 only): blockIdx.y selects the K range [y k_len, (y + 1) k_len) and the
 // fp32 sums go to ws[y][M][16 gridDim.x] instead of out.
-template <int CODE, int EPI, int WAVES>
+template <int CODE, int EPI, int WAVES, bool XL = false>
 __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
         const uint16_t* __restrict__ x, long x_stride, const uint16_t* __restrict__ w,
         const uint16_t* __restrict__ bias, uint16_t* __restrict__ out, long o_stride, int M,
@@ -51,6 +51,21 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
     const uint16_t* wp0 = w + (long)(n0 + c16) * K + koff;
     const uint16_t* wp1 = w + (long)(up_row_offset + n0 + c16) * K + koff;
     const uint16_t* xp = x + (long)min(c16, M - 1) * x_stride + koff;
+    // XL: every wave first copies its K slice of the x rows into LDS and takes its A fragments
+    // from there, which leaves the vector-memory queue to the weight stream
+    extern __shared__ __attribute__((aligned(16))) uint16_t xs_all[];
+    const int xs_pitch = kslice + 8;                         // elements; rows 16 B apart in banks
+    uint16_t* xs = xs_all + (long)wv * M * xs_pitch;
+    if (XL) {
+        for (int r = 0; r < M; ++r) {
+            const uint16_t* src = x + (long)r * x_stride + (long)blockIdx.y * k_len + (long)wv * kslice;
+            for (int c = lane * 8; c < kslice; c += 512)
+                *reinterpret_cast<u32x4_t*>(xs + r * xs_pitch + c) =
+                    *reinterpret_cast<const u32x4_t*>(src + c);
+        }
+        __syncthreads();
+    }
+    const uint16_t* xl = xs + min(c16, M - 1) * xs_pitch + 8 * q4;
 
     f32x4_t acc[NB];
 #pragma unroll
@@ -69,7 +84,8 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
                 bw[0][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp0 + k + 32 * u));
                 if (NB == 2)
                     bw[NB - 1][u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wp1 + k + 32 * u));
-                ax[u] = *reinterpret_cast<const u32x4_t*>(xp + k + 32 * u);
+                ax[u] = XL ? *reinterpret_cast<const u32x4_t*>(xl + k + 32 * u)
+                           : *reinterpret_cast<const u32x4_t*>(xp + k + 32 * u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -122,6 +138,7 @@ __global__ __launch_bounds__(WAVES * 64) void skinny_gemm_kernel(
 }
 
 int g_force_waves = 0;        // tuning aid (mvl_skinny_gemm_force_waves): 0 = automatic choice
+int g_force_xl = 0;           // x staged in LDS: 0 = automatic, 1 = whenever it fits, -1 = never
 
 template <int CODE, int EPI>
 int launch(const void* x, long xs, const void* w, const void* bias, void* out, long os, int M,
@@ -137,8 +154,29 @@ int launch(const void* x, long xs, const void* w, const void* bias, void* out, l
     const int waves = g_force_waves ? g_force_waves : (K % 256 == 0 ? 8 : 4);
     if (waves == 16 && K % 512 == 0)
         skinny_gemm_kernel<CODE, EPI, 16><<<tiles, 16 * 64, 0, st>>>(X, xs, W, B, O, os, M, KT, up_off, ws, K);
-    else if (waves == 8 && K % 256 == 0)
-        skinny_gemm_kernel<CODE, EPI, 8><<<tiles, 8 * 64, 0, st>>>(X, xs, W, B, O, os, M, KT, up_off, ws, K);
+    else if (waves == 8 && K % 256 == 0) {
+        // x staged in LDS (plain epilogue) when the rows fit: <= 80 KB keeps two workgroups on
+        // a CU; a grid of at most one workgroup per CU may take up to 136 KB.  Measured on the
+        // Qwen3-8B projections at 1-4 rows: qkv 13.8 -> 13.2 us, o 9.5 -> 8.9, down 25.6 -> 23.3
+        // (the x loads no longer take places in the vector-memory queue); the SwiGLU form,
+        // which has three times the workgroups, gains nothing and keeps its x in registers.
+        const size_t lds = (size_t)M * (K + 64) * 2;
+        const bool one_per_cu = (long)tiles.x * tiles.y <= 256;
+        const bool xl = g_force_xl >= 0 && (EPI == 0 || g_force_xl > 0)
+                        && lds <= (size_t)(one_per_cu ? 136 : 80) * 1024;
+        if (xl) {
+            auto kern = skinny_gemm_kernel<CODE, EPI, 8, true>;
+            static bool attr_set = false;
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        136 * 1024) != hipSuccess) return -1;
+                attr_set = true;
+            }
+            kern<<<tiles, 8 * 64, lds, st>>>(X, xs, W, B, O, os, M, KT, up_off, ws, K);
+        } else {
+            skinny_gemm_kernel<CODE, EPI, 8><<<tiles, 8 * 64, 0, st>>>(X, xs, W, B, O, os, M, KT, up_off, ws, K);
+        }
+    }
     else if (K % 128 == 0)
         skinny_gemm_kernel<CODE, EPI, 4><<<tiles, 4 * 64, 0, st>>>(X, xs, W, B, O, os, M, KT, up_off, ws, K);
     else
@@ -149,6 +187,7 @@ int launch(const void* x, long xs, const void* w, const void* bias, void* out, l
 }  // namespace
 
 extern "C" void mvl_skinny_gemm_force_waves(int waves) { g_force_waves = waves; }
+extern "C" void mvl_skinny_gemm_force_x_lds(int mode) { g_force_xl = mode; }
 
 // epilogue 0: out[M, N] = x . W^T (+ bias);  W is [N, K] row-major, N % 16 == 0.
 // epilogue 1: W is [2 I, K] (gate rows then up rows), out[M, I] = silu(x.Wg^T) * (x.Wu^T).
