@@ -243,6 +243,7 @@ def _q_rope_args(q: torch.Tensor, q_rope):
     assert positions.numel() >= q.shape[0] and positions.is_contiguous()
     if q_weight is not None:
         assert q_weight.dtype == q.dtype and q_weight.numel() == q.shape[-1] and q_weight.is_contiguous()
+        assert q_weight.data_ptr() % 16 == 0
     # keep the converted positions alive until the launch has been issued
     return positions, cos_sin.data_ptr(), q_weight.data_ptr() if q_weight is not None else None, float(eps)
 
