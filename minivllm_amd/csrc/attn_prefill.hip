@@ -115,48 +115,6 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
         for (int s = 0; s < KSTEPS; ++s)
             qfrag[s] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(qp + 16 * s + 8 * hh));
     }
-    // ---- q/k-norm + RoPE of the Q rows, fused here: a Q row is read by exactly one workgroup,
-    //      so the projection's output never has to be rewritten in place and read again (K is
-    //      shared by many workgroups and is transformed by the store kernel beforehand).  Pairs
-    //      (e, e + D/2) of a row sit in one lane: fragments s and s + KSTEPS/2.
-    if (a.cos_sin != nullptr) {
-        float f[KSTEPS][8];
-        float ss = 0.f;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            unpack8<CODE>(__builtin_bit_cast(u32x4_t, qfrag[s]), f[s]);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) ss += f[s][i] * f[s][i];
-        }
-        ss += __shfl_xor(ss, 32, 64);                    // the other half of the row
-        if (a.q_w != nullptr) {
-            const float rstd = rsqrtf(ss / (float)D + a.eps);
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                float wv[8];
-                unpack8<CODE>(*reinterpret_cast<const u32x4_t*>(a.q_w + 16 * s + 8 * hh), wv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) f[s][i] *= rstd * wv[i];
-            }
-        }
-        const float* cs = a.cos_sin + (long)a.positions[q_start + my_q_c] * D;
-#pragma unroll
-        for (int s = 0; s < KSTEPS / 2; ++s) {
-            const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh);
-            const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh + 4);
-            const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh);
-            const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh + 4);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float c = i < 4 ? c0[i] : c1[i - 4], sn = i < 4 ? s0[i] : s1[i - 4];
-                const float x1 = f[s][i], x2 = f[s + KSTEPS / 2][i];
-                f[s][i] = x1 * c - x2 * sn;
-                f[s + KSTEPS / 2][i] = x1 * sn + x2 * c;
-            }
-        }
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) qfrag[s] = __builtin_bit_cast(vec8, pack8<CODE>(f[s]));
-    }
     const int my_pos = my_q + pos_off;                   // last key this row may see
     const int wave_min_pos = q0 + 32 * w + pos_off;
     const int wave_max_pos = min(q0 + 32 * w + 31, q_len - 1) + pos_off;
@@ -214,12 +172,64 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[n][e] = 0.f;
 
+    // fused Q transform: the rotary table row of the lane's query is requested here, ahead of
+    // the first tile
+    f32x4_t cs_raw[KSTEPS / 2][4];
+    if (a.cos_sin != nullptr) {
+        const float* cs = a.cos_sin + (long)a.positions[q_start + my_q_c] * D;
+#pragma unroll
+        for (int s = 0; s < KSTEPS / 2; ++s) {
+            cs_raw[s][0] = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh);
+            cs_raw[s][1] = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh + 4);
+            cs_raw[s][2] = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh);
+            cs_raw[s][3] = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh + 4);
+        }
+    }
+
     int ids_next[ITER];
     {
         int ids[ITER];
         load_block_ids(0, ids);
         stage_tile(0, ids);
         if (n_tiles > 1) load_block_ids(1, ids_next);
+    }
+    // ---- q-norm + RoPE of the Q rows, fused here: a Q row is read by exactly one workgroup,
+    //      so the projection's output never has to be rewritten in place and read again (K is
+    //      shared by many workgroups and is transformed by the store kernel beforehand).  Pairs
+    //      (e, e + D/2) of a row sit in one lane: fragments s and s + KSTEPS/2.  The table row
+    //      was requested before the first tile's DMA; the arithmetic runs in that DMA's shadow.
+    if (a.cos_sin != nullptr) {
+        float f[KSTEPS][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            unpack8<CODE>(__builtin_bit_cast(u32x4_t, qfrag[s]), f[s]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += f[s][i] * f[s][i];
+        }
+        ss += __shfl_xor(ss, 32, 64);                    // the other half of the row
+        if (a.q_w != nullptr) {
+            const float rstd = rsqrtf(ss / (float)D + a.eps);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                float wv[8];
+                unpack8<CODE>(*reinterpret_cast<const u32x4_t*>(a.q_w + 16 * s + 8 * hh), wv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) f[s][i] *= rstd * wv[i];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS / 2; ++s) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float c = cs_raw[s][i >> 2][i & 3], sn = cs_raw[s][2 + (i >> 2)][i & 3];
+                const float x1 = f[s][i], x2 = f[s + KSTEPS / 2][i];
+                f[s][i] = x1 * c - x2 * sn;
+                f[s + KSTEPS / 2][i] = x1 * sn + x2 * c;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) qfrag[s] = __builtin_bit_cast(vec8, pack8<CODE>(f[s]));
     }
     __syncthreads();                         // drains the LDS-DMA (vmcnt) and meets the waves
     MVL_PROBE(1, wall_clock64());
