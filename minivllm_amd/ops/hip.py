@@ -78,6 +78,9 @@ _skinny_norm = _sig("mvl_skinny_norm_gemm", _c_void, _c_long, _c_void, _c_long, 
 _mid = _sig("mvl_mid_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_void, _c_int,
             _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void)
 
+_big = _sig("mvl_big_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_int, _c_int,
+            _c_int, _c_int, _c_int, _c_void)
+
 _mid_eff_splits = _lib.mvl_mid_effective_splits
 _mid_eff_splits.argtypes = [_c_int, _c_int]
 _mid_eff_splits.restype = _c_int
@@ -894,3 +897,48 @@ def sample_local(logits: torch.Tensor, temperatures: torch.Tensor, seed: int, st
 
 def sample(logits: torch.Tensor, temperatures: torch.Tensor, seed: int = 0, step=0) -> torch.Tensor:
     return sample_local(logits, temperatures, seed, step)[1].to(torch.int64)
+
+
+# ------------------------------------------------------------ prefill-sized GEMM
+BIG_MIN_ROWS = 257                    # below this the weight-streaming kernels / the library serve
+
+
+def big_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
+    """Operands the 256 x 256-tile kernel can take: 2-D 16-bit row-major x (row stride a multiple
+    of 8 elements) and contiguous weights of the same dtype, K a multiple of 64 and >= 128, the
+    output width (per SwiGLU half: N / 2) a multiple of 256 (128), operands below 4 GiB."""
+    if x.dim() != 2 or weight.dim() != 2 or x.dtype not in _DT or weight.dtype != x.dtype:
+        return False
+    M, K = x.shape
+    N = weight.shape[0]
+    if weight.shape[1] != K or not weight.is_contiguous() or x.stride(1) != 1 or x.stride(0) % 8:
+        return False
+    if K % 64 or K < 128 or M < 1:
+        return False
+    if swiglu:
+        if N % 2 or (N // 2) % 128:
+            return False
+    elif N % 256:
+        return False
+    return M * x.stride(0) * 2 < (1 << 32) and N * K * 2 < (1 << 32)
+
+
+def big_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               swiglu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x @ weight.T (+ bias)``, or with ``swiglu`` ``silu(x @ Wg.T) * (x @ Wu.T)`` of the fused
+    ``[Wg; Wu]`` weight, on the compute-bound 256 x 256-tile MFMA kernel (any row count; built
+    for prefill steps)."""
+    if not big_gemm_ok(x, weight, swiglu):
+        raise ValueError(f"big_linear cannot take x {tuple(x.shape)} / weight {tuple(weight.shape)}")
+    M, K = x.shape
+    N = weight.shape[0]
+    n_out = N // 2 if swiglu else N
+    if out is None:
+        out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
+    assert out.shape == (M, n_out) and out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.dtype == x.dtype
+    if bias is not None:
+        assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
+    _check(_big(x.data_ptr(), x.stride(0), weight.data_ptr(),
+                bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
+                M, N, K, int(swiglu), _dt(x), _stream()), "big_gemm")
+    return out
