@@ -24,15 +24,20 @@
 //    address of the DMA (its destination is lane-linear) and on the fragment reads;
 //  * the product is computed transposed (MFMA A operand = W rows, B operand = x rows): a lane
 //    holds 4 consecutive output columns of a row;
-//  * workgroup ids are remapped so that the ids sharing an XCD (id mod 8) cover a compact block
-//    of tiles (panels of 8 row tiles walked column by column): each XCD's L2 then serves an x
-//    panel to 4 column tiles and a W panel to 8 row tiles at a time.
+//  * the grid is one workgroup per CU; a workgroup walks tiles g, g + G, ... of a logical order
+//    (panels of 8 row tiles walked column by column) in which the workgroups that share an XCD
+//    (id mod 8) hold a compact block of 32 tiles at any time, so each XCD's L2 serves an x panel
+//    to 4 column tiles and a W panel to 8 row tiles.  The half-tile pipeline runs on across tile
+//    boundaries: the last two K-tiles of a tile already request the first K-tiles of the next
+//    one, and the stores of a finished tile drain under the next tile's MFMAs (rows beyond M
+//    are dropped by the range check of the buffer stores).
 //
 // Call sites: the MLP's gate_up projection on prefill steps (the reference's
 // F.linear + SiluAndMul, src/myvllm/layers/linear.py:109, src/myvllm/layers/activation.py:8-16),
 // and any projection for which the start-up measurement prefers it to the library.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 using namespace mvl;
 
@@ -42,15 +47,18 @@ constexpr int kBigThreads = 512;
 constexpr int kHalf = 128 * 128;            // bytes of a half-tile
 constexpr int kBuf = 4 * kHalf;             // one K-tile: A0 B0 B1 A1
 constexpr int kBigBK = 64;
+constexpr int kBigLds = 2 * kBuf + 8 * 4096;   // two K-tiles + a 4 KiB output block per wave
 
 struct BigArgs {
     const uint16_t* x; long x_stride;       // [M, K], row stride in elements
     const uint16_t* w;                      // [N, K] row-major
     const uint16_t* bias;                   // may be null
     uint16_t* out; long o_stride;
+    unsigned out_bytes;                     // extent of `out` for the store range check
     int M, N, K;
     int up_off;                             // SwiGLU: row of W where the up projection starts
-    int tiles_m, tiles_n, ktiles;
+    int tiles_m, tiles_n, tiles, ktiles;
+    int probe;                              // measurement only: 1 every tile loads tile 0's operands, 2 no stores
 };
 
 template <int N>
@@ -66,6 +74,11 @@ __device__ __forceinline__ void big_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// per-lane DMA source offsets of one output tile (32-bit byte offsets from x / W)
+struct BigSrc {
+    uint32_t a[2][2], b[2][2];              // [half][piece]
+};
+
 template <int CODE, bool SWI>
 __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void big_gemm_kernel(BigArgs a) {
@@ -76,13 +89,18 @@ void big_gemm_kernel(BigArgs a) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wr = wv >> 2, wc = wv & 3;
+    const int G = gridDim.x, bid = blockIdx.x;
 
-    // ---- tile of this workgroup
-    int tm, tn;
-    {
-        const int nwg = gridDim.x, bid = blockIdx.x;
-        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-        const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    // ---- tile walk.  Round rd covers logical tiles [rd G, rd G + cnt); inside a round the
+    // workgroups with equal (id mod 8) take consecutive logical tiles.
+    auto tile_id = [&](int rd) -> int {
+        const int base = rd * G;
+        const int cnt = min(G, a.tiles - base);
+        if (bid >= cnt) return -1;
+        const int q = cnt >> 3, r = cnt & 7, xcd = bid & 7;
+        return base + (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    };
+    auto tile_pos = [&](int id, int& tm, int& tn) {
         constexpr int PM = 8;
         const int per_panel = PM * a.tiles_n;
         const int panel = id / per_panel;
@@ -90,41 +108,50 @@ void big_gemm_kernel(BigArgs a) {
         const int rows = min(PM, a.tiles_m - panel * PM);
         tn = rem / rows;
         tm = panel * PM + rem - tn * rows;
-    }
-    const int m0 = tm * 256;
-    const int n0 = SWI ? tn * 128 : tn * 256;          // first W row of half B0
+    };
 
     // ---- DMA sources.  A piece is 8 rows x 128 bytes; lane l moves chunk (l & 7) of image row
     // (l >> 3), which holds global chunk (l & 7) ^ (l >> 3).  Wave w moves pieces 2w, 2w + 1 of
-    // each half-tile.  Offsets are 32-bit byte offsets from a uniform base that walks along K.
+    // each half-tile.
     const int prow = lane >> 3;
     const int pchunk = (lane & 7) ^ prow;
-    uint32_t off_a[2][2], off_b[2][2];
+    auto tile_src = [&](int tm, int tn, BigSrc& s) {
+        if (a.probe & 1) tm = tn = 0;
+        const int m0 = tm * 256;
+        const int n0 = SWI ? tn * 128 : tn * 256;
 #pragma unroll
-    for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < 2; ++h)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int r = h * 128 + (wv * 2 + i) * 8 + prow;
-            const int xr = min(m0 + r, a.M - 1);                        // rows >= M: duplicates
-            off_a[h][i] = (uint32_t)xr * (uint32_t)(a.x_stride * 2) + pchunk * 16;
-            int wrow = SWI ? (h ? a.up_off : 0) + n0 + (r & 127) : n0 + r;
-            wrow = min(wrow, a.N - 1);
-            off_b[h][i] = (uint32_t)wrow * (uint32_t)(a.K * 2) + pchunk * 16;
-        }
+            for (int i = 0; i < 2; ++i) {
+                const int r = h * 128 + (wv * 2 + i) * 8 + prow;
+                const int xr = min(m0 + r, a.M - 1);                    // rows >= M: duplicates
+                s.a[h][i] = (uint32_t)xr * (uint32_t)(a.x_stride * 2) + pchunk * 16;
+                // image row r of half h <-> W row: SwiGLU gate / up column r; plain: wave wc's 64
+                // consecutive columns are rows 32 wc .. +31 of B0 (first 32) and of B1 (last 32)
+                const int r7 = r & 127;
+                const int wrow = SWI ? (h ? a.up_off : 0) + n0 + r7
+                                     : n0 + (r7 >> 5) * 64 + h * 32 + (r7 & 31);
+                s.b[h][i] = (uint32_t)wrow * (uint32_t)(a.K * 2) + pchunk * 16;
+            }
+    };
     const char* xk = reinterpret_cast<const char*>(a.x);
     const char* wk = reinterpret_cast<const char*>(a.w);
 
-    // request half-tile J (0 A0, 1 B0, 2 B1, 3 A1) of the K-tile at byte offset kb into the
-    // buffer at LDS byte offset bofs (wave-uniform)
-    auto stage = [&](int bofs, auto j_c, long kb) {
+    // request half-tile J (0 A0, 1 B0, 2 B1, 3 A1) of K-tile k of this workgroup's current tile
+    // (or, with `next`, of its next tile) into the buffer at LDS byte offset bofs; bofs, k and
+    // next are wave-uniform
+    BigSrc cur, nxt;
+    auto stage = [&](int bofs, auto j_c, bool next, int k) {
         constexpr int J = decltype(j_c)::value;
         constexpr bool is_a = (J == 0 || J == 3);
         constexpr int h = (J == 2 || J == 3) ? 1 : 0;
         char* dst = smem + bofs + J * kHalf + wv * 2048;
+        const long kb = (long)k * (kBigBK * 2);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const char* src = (is_a ? xk : wk) + kb + (is_a ? off_a[h][i] : off_b[h][i]);
-            glds16(src, dst + i * 1024);
+            const uint32_t off = is_a ? (next ? nxt.a[h][i] : cur.a[h][i])
+                                      : (next ? nxt.b[h][i] : cur.b[h][i]);
+            glds16((is_a ? xk : wk) + kb + off, dst + i * 1024);
         }
     };
 
@@ -135,13 +162,6 @@ void big_gemm_kernel(BigArgs a) {
     const int b_off = lane_off0 + wc * (32 * 128);
 
     f32x4_t acc[4][2][4];                    // [quadrant TL TR BR BL][W block][x block]
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) acc[q][n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-
     vec8 af[2][4], bl[2][2], br[2][2];       // [k half][block]
 
     auto read_a = [&](int bofs, auto j_c) {
@@ -182,134 +202,233 @@ void big_gemm_kernel(BigArgs a) {
     using I2 = std::integral_constant<int, 2>;
     using I3 = std::integral_constant<int, 3>;
 
-    // One K-tile (index u, in buffer u & 1).  MODE 0: tiles u + 1 and u + 2 exist; 1: u + 1 is
-    // the last tile; 2: u is the last tile.  The vmcnt values count 2 instructions per half-tile
-    // requested after the one that the next phase reads.
-    auto ktile = [&](auto mode_c, int u) {
-        constexpr int MODE = decltype(mode_c)::value;
-        const int B = (u & 1) * kBuf, NB = kBuf - B;
-        const long kb1 = (long)(u + 1) * (kBigBK * 2), kb2 = (long)(u + 2) * (kBigBK * 2);
+    // One K-tile, the g-th of this workgroup (buffer g & 1); u = its index inside the tile.
+    // It requests the halves B1 / A1 of the K-tile that follows it in the workgroup's sequence
+    // and A0 / B0 of the one after that (both may belong to the next tile).  A wait names the
+    // half-tile the NEXT phase reads: 4 half-tiles (8 instructions) were requested after it, and
+    // loads complete in order, so at most 8 outstanding instructions means it has landed
+    // (whatever the epilogue's stores do: a store still pending only makes the wait stricter).
+    // FIRST: the tile's first K-tile.  Every earlier request was waited for before the previous
+    // tile's epilogue, so this K-tile waits for nothing: the first counted wait after the
+    // epilogue's stores (which it would force to complete) comes a whole K-tile later.
+    auto ktile = [&](auto first_c, int g, int u, int nk) {
+        constexpr bool FIRST = decltype(first_c)::value != 0;
+        const int B = (g & 1) * kBuf, NB = kBuf - B;
+        const bool n1 = u + 1 >= nk, n2 = u + 2 >= nk;
+        const int k1 = n1 ? u + 1 - nk : u + 1, k2 = n2 ? u + 2 - nk : u + 2;
         // phase 1: (top, left)
         read_b(B, I1{}, bl);
         read_a(B, I0{});
-        if (MODE < 2) stage(NB, I2{}, kb1);
-        if (MODE < 2) big_wait_vmcnt<8>(); else big_wait_vmcnt<2>();
+        stage(NB, I2{}, n1, k1);
+        if (!FIRST) big_wait_vmcnt<8>();
         big_barrier();
         mfma_quadrant(I0{}, bl);
         big_barrier();
         // phase 2: (top, right)
         read_b(B, I2{}, br);
-        if (MODE < 2) stage(NB, I3{}, kb1);
-        if (MODE < 2) big_wait_vmcnt<8>(); else big_wait_vmcnt<0>();
+        stage(NB, I3{}, n1, k1);
+        if (!FIRST) big_wait_vmcnt<8>();
         big_barrier();
         mfma_quadrant(I1{}, br);
         big_barrier();
         // phase 3: (bottom, right)
         read_a(B, I3{});
-        if (MODE == 0) stage(B, I0{}, kb2);
+        stage(B, I0{}, n2, k2);
         big_barrier();
         mfma_quadrant(I2{}, br);
         big_barrier();
         // phase 4: (bottom, left), no reads
-        if (MODE == 0) stage(B, I1{}, kb2);
-        if (MODE == 0) big_wait_vmcnt<8>(); else if (MODE == 1) big_wait_vmcnt<4>();
+        stage(B, I1{}, n2, k2);
+        if (!FIRST) big_wait_vmcnt<8>();
         big_barrier();
         mfma_quadrant(I3{}, bl);
         big_barrier();
     };
 
-    // ---- prologue: K-tile 0 complete, A0 / B0 of K-tile 1
-    stage(0, I0{}, 0); stage(0, I1{}, 0); stage(0, I2{}, 0); stage(0, I3{}, 0);
-    stage(kBuf, I0{}, kBigBK * 2); stage(kBuf, I1{}, kBigBK * 2);
-    big_wait_vmcnt<8>();
+    const __amdgpu_buffer_rsrc_t orsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+
+    // acc[q][n][m][e] = out[row 16 m + frow][col 16 n + 4 fq + e] of quadrant q: 0 (top, left)
+    // 1 (top, right) 2 (bottom, right) 3 (bottom, left).  A wave's output is 128 rows x 64
+    // consecutive columns (SwiGLU: 32, gate quadrant 0 / 3 paired with up quadrant 1 / 2).  It
+    // goes through a wave-private 4 KiB LDS block (32 rows x 128 B, SwiGLU 64 rows x 64 B; 16-byte
+    // chunks XOR-ed with the row so that neither the 8-byte writes nor the 16-byte reads pile up
+    // on a bank) and leaves as 16-byte stores that cover whole rows of the block: 8-byte stores
+    // straight from the accumulator layout cost 4x the write requests, which the L2 channels
+    // could not absorb (0.6B qkv at 16384 rows: 127 us with them, 98 us without any store).
+    char* const ep = smem + 2 * kBuf + wv * 4096;
+    auto epilogue = [&](int tm, int tn) {
+        if (a.probe & 2) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) asm volatile("" ::"v"(acc[q][n][m]));
+            return;
+        }
+        const int m0 = tm * 256;
+        constexpr int ROWB = SWI ? 64 : 128;                 // bytes per row of the block
+        constexpr int LPRW = ROWB / 16;                      // lanes per row on the way out
+        constexpr int RPI = 64 / LPRW;                       // rows per store instruction
+        const int col_base = SWI ? tn * 128 + wc * 32 : tn * 256 + wc * 64;
+        // bias of this lane's columns: [side][n][e]
+        float bias_v[2][2][4];
+#pragma unroll
+        for (int sd = 0; sd < 2; ++sd)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias_v[sd][n][e] = 0.f;
+                if (a.bias != nullptr) {
+                    const int col = SWI ? (sd ? a.up_off : 0) + col_base + n * 16 + 4 * fq
+                                        : col_base + sd * 32 + n * 16 + 4 * fq;
+                    const u32x2_t b = *reinterpret_cast<const u32x2_t*>(a.bias + col);
+                    unpack2<CODE>(b[0], bias_v[sd][n][0], bias_v[sd][n][1]);
+                    unpack2<CODE>(b[1], bias_v[sd][n][2], bias_v[sd][n][3]);
+                }
+            }
+        const int orow = lane / LPRW, ochunk = lane % LPRW;
+#pragma unroll
+        for (int hb = 0; hb < 2; ++hb) {                     // top / bottom rows of the wave
+            const int ql = hb ? 3 : 0, qr = hb ? 2 : 1;      // left (gate) / right (up) quadrant
+#pragma unroll
+            for (int blk = 0; blk < (SWI ? 1 : 2); ++blk) {  // plain: x blocks {0,1} then {2,3}
+                // ---- accumulators -> block
+#pragma unroll
+                for (int mi = 0; mi < (SWI ? 4 : 2); ++mi) {
+                    const int m = SWI ? mi : blk * 2 + mi;
+                    const int rr = mi * 16 + frow;           // row of the block
+#pragma unroll
+                    for (int sd = 0; sd < (SWI ? 1 : 2); ++sd)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n) {
+                            float r[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (SWI) {
+                                    const float g = acc[ql][n][m][e] + bias_v[0][n][e];
+                                    const float up = acc[qr][n][m][e] + bias_v[1][n][e];
+                                    r[e] = g * __builtin_amdgcn_rcpf(1.f + __expf(-g)) * up;
+                                } else {
+                                    r[e] = acc[sd ? qr : ql][n][m][e] + bias_v[sd][n][e];
+                                }
+                            }
+                            u32x2_t o;
+                            o[0] = pack2<CODE>(r[0], r[1]);
+                            o[1] = pack2<CODE>(r[2], r[3]);
+                            const int cb = (sd * 32 + n * 16 + 4 * fq) * 2;      // byte column
+                            const int chunk = (cb >> 4) ^ (SWI ? ((rr >> 1) & 3) : (rr & 7));
+                            *reinterpret_cast<u32x2_t*>(ep + rr * ROWB + chunk * 16 + (cb & 15)) = o;
+                        }
+                }
+                // ---- block -> memory, RPI whole rows per instruction
+#pragma unroll
+                for (int i = 0; i < 4096 / ROWB / RPI; ++i) {
+                    const int rr = i * RPI + orow;
+                    const int chunk = ochunk ^ (SWI ? ((rr >> 1) & 3) : (rr & 7));
+                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + rr * ROWB + chunk * 16);
+                    const int row = m0 + hb * 128 + wr * 64 + (SWI ? 0 : blk * 32) + rr;
+                    // rows >= M lie beyond out_bytes: the range check drops them
+                    const uint32_t voff = (uint32_t)row * (uint32_t)(a.o_stride * 2)
+                                          + (uint32_t)(col_base * 2 + ochunk * 16);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, (int)voff, 0, 0);
+                }
+            }
+        }
+    };
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) acc[q][n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    };
+
+    // ---- this workgroup's tiles
+    int id = tile_id(0);
+    if (id < 0) return;                      // uniform over the workgroup
+    int tm, tn;
+    tile_pos(id, tm, tn);
+    tile_src(tm, tn, cur);
+    const int nk = a.ktiles;                 // >= 4
+
+    // prologue: K-tile 0 complete, A0 / B0 of K-tile 1 on their way
+    stage(0, I0{}, false, 0); stage(0, I1{}, false, 0); stage(0, I2{}, false, 0); stage(0, I3{}, false, 0);
+    stage(kBuf, I0{}, false, 1); stage(kBuf, I1{}, false, 1);
+    big_wait_vmcnt<0>();
     big_barrier();
     if (wr == 1) big_barrier();              // the second wave row runs one barrier behind
 
-    const int nk = a.ktiles;
-    for (int u = 0; u < nk - 2; ++u) ktile(I0{}, u);
-    ktile(I1{}, nk - 2);
-    ktile(I2{}, nk - 1);
-    if (wr == 0) big_barrier();
-
-    // ---- epilogue: acc[q][n][m][e] = out[row of x block m][col 16 n + 4 fq + e of the quadrant]
-    // quadrants: 0 (top, left) 1 (top, right) 2 (bottom, right) 3 (bottom, left)
-#pragma unroll
-    for (int q = 0; q < (SWI ? 2 : 4); ++q) {
-        // SwiGLU pairs quadrant 0 with 1 (top rows) and 3 with 2 (bottom rows)
-        const int qg = SWI ? (q == 0 ? 0 : 3) : q;          // gate / plain quadrant
-        const int qu = SWI ? (q == 0 ? 1 : 2) : q;          // up quadrant
-        const bool bottom = (qg == 2 || qg == 3);
-        const bool right = (qg == 1 || qg == 2);
-        const int row0 = m0 + (bottom ? 128 : 0) + wr * 64 + frow;
-        const int col0 = SWI ? tn * 128 + wc * 32 + 4 * fq
-                             : tn * 256 + (right ? 128 : 0) + wc * 32 + 4 * fq;
-#pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int col = col0 + n * 16;
-            float bg[4] = {0.f, 0.f, 0.f, 0.f}, bu[4] = {0.f, 0.f, 0.f, 0.f};
-            if (a.bias != nullptr) {
-                const u32x2_t b = *reinterpret_cast<const u32x2_t*>(a.bias + col);
-                unpack2<CODE>(b[0], bg[0], bg[1]); unpack2<CODE>(b[1], bg[2], bg[3]);
-                if (SWI) {
-                    const u32x2_t c = *reinterpret_cast<const u32x2_t*>(a.bias + a.up_off + col);
-                    unpack2<CODE>(c[0], bu[0], bu[1]); unpack2<CODE>(c[1], bu[2], bu[3]);
-                }
-            }
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const int row = row0 + m * 16;
-                if (row >= a.M) continue;
-                float r[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float g = acc[qg][n][m][e] + bg[e];
-                    if (SWI) {
-                        const float up = acc[qu][n][m][e] + bu[e];
-                        r[e] = g / (1.f + __expf(-g)) * up;
-                    } else {
-                        r[e] = g;
-                    }
-                }
-                u32x2_t o;
-                o[0] = pack2<CODE>(r[0], r[1]);
-                o[1] = pack2<CODE>(r[2], r[3]);
-                *reinterpret_cast<u32x2_t*>(a.out + (long)row * a.o_stride + col) = o;
-            }
-        }
+    int g = 0;                               // K-tiles done by this workgroup (buffer parity)
+    for (int rd = 0;; ++rd) {
+        const int nid = tile_id(rd + 1);
+        int ntm = tm, ntn = tn;
+        if (nid >= 0) tile_pos(nid, ntm, ntn);
+        tile_src(ntm, ntn, nxt);             // the last tile requests its own first K-tiles again
+        zero_acc();
+        ktile(I1{}, g, 0, nk);
+        ++g;
+        for (int u = 1; u < nk; ++u, ++g) ktile(I0{}, g, u, nk);
+        // every request so far (up to A0 / B0 of the next tile's second K-tile) lands before
+        // the stores are issued: loads and stores do not complete in a common order, so a
+        // counted wait behind the stores would have to wait for all of them
+        big_wait_vmcnt<0>();
+        epilogue(tm, tn);
+        if (nid < 0) break;
+        cur = nxt; tm = ntm; tn = ntn;
     }
+    if (wr == 0) big_barrier();
+    big_wait_vmcnt<0>();
 }
 
 template <int CODE, bool SWI>
 int big_launch(BigArgs a, hipStream_t st) {
     auto k = big_gemm_kernel<CODE, SWI>;
     static const hipError_t once = hipFuncSetAttribute(
-        (const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kBuf);
+        (const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds);
     if (once != hipSuccess) return (int)once;
-    k<<<a.tiles_m * a.tiles_n, kBigThreads, 2 * kBuf, st>>>(a);
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return -2;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    const int grid = a.tiles < cus ? a.tiles : cus;
+    k<<<grid, kBigThreads, kBigLds, st>>>(a);
     return MVL_CHECK_LAUNCH();
 }
 
 }  // namespace
 
 // out[M, N_out] = x . W^T (+ bias)  [swiglu: W = [gate; up], N_out = N / 2].
-// K a multiple of 64 and >= 128; N (N / 2 with swiglu) a multiple of 128... see the checks.
+// K a multiple of 64 and >= 256; N a multiple of 256 (swiglu: N / 2 a multiple of 128); x rows
+// and out rows 16-byte aligned; x, W and out below 4 GiB each.
 extern "C" int mvl_big_gemm(const void* x, long x_stride, const void* w, const void* bias,
                             void* out, long o_stride, int M, int N, int K, int swiglu, int dtype,
                             void* stream) {
     if (M == 0) return 0;
-    if (M < 0 || K % kBigBK != 0 || K < 2 * kBigBK || (dtype != 0 && dtype != 1)) return -1;
+    if (M < 0 || K % kBigBK != 0 || K < 4 * kBigBK || (dtype != 0 && dtype != 1)) return -1;
     if (swiglu ? (N % 2 != 0 || (N / 2) % 128 != 0) : (N % 256 != 0)) return -1;
-    if (x_stride % 8 != 0 || o_stride % 4 != 0) return -1;
-    // 32-bit byte offsets inside the operands
-    if ((double)M * (double)x_stride * 2.0 >= 4294967296.0 || (double)N * (double)K * 2.0 >= 4294967296.0)
+    if (x_stride % 8 != 0 || o_stride % 8 != 0) return -1;
+    const int n_out = swiglu ? N / 2 : N;
+    const double out_bytes = ((double)(M - 1) * (double)o_stride + n_out) * 2.0;
+    if ((double)M * (double)x_stride * 2.0 >= 4294967296.0 || (double)N * (double)K * 2.0 >= 4294967296.0
+        || out_bytes >= 2147483648.0)
         return -1;
     BigArgs a;
     a.x = (const uint16_t*)x; a.x_stride = x_stride; a.w = (const uint16_t*)w;
     a.bias = (const uint16_t*)bias; a.out = (uint16_t*)out; a.o_stride = o_stride;
+    a.out_bytes = (unsigned)out_bytes;
     a.M = M; a.N = N; a.K = K; a.up_off = N / 2;
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = swiglu ? (N / 2) / 128 : N / 256;
+    a.tiles = a.tiles_m * a.tiles_n;
     a.ktiles = K / kBigBK;
+    static const char* probe_env = getenv("MVL_BIG_PROBE");
+    a.probe = probe_env ? atoi(probe_env) : 0;
     auto st = (hipStream_t)stream;
     if (dtype == 0) return swiglu ? big_launch<0, true>(a, st) : big_launch<0, false>(a, st);
     return swiglu ? big_launch<1, true>(a, st) : big_launch<1, false>(a, st);

@@ -935,7 +935,7 @@ def big_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     n_out = N // 2 if swiglu else N
     if out is None:
         out = torch.empty((M, n_out), dtype=x.dtype, device=x.device)
-    assert out.shape == (M, n_out) and out.stride(1) == 1 and out.stride(0) % 4 == 0 and out.dtype == x.dtype
+    assert out.shape == (M, n_out) and out.stride(1) == 1 and out.stride(0) % 8 == 0 and out.dtype == x.dtype
     if bias is not None:
         assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
     _check(_big(x.data_ptr(), x.stride(0), weight.data_ptr(),
