@@ -166,6 +166,10 @@ class EngineConfig:
     # GPU only: at start-up, time the hand-written weight-streaming GEMM against the library on
     # this model's own projections (1-16 rows) and use whichever is faster per shape
     tune_decode_gemms: bool = True
+    # GPU only: at start-up, time the hand-written 256 x 256-tile GEMM (csrc/big_gemm.hip; with
+    # the SwiGLU epilogue for gate_up) against the library (+ activation kernel) on this model's
+    # projections at prefill-sized row counts and use whichever is faster per shape and row bucket
+    tune_prefill_gemms: bool = True
     # GPU only, experimental: multiply each layer norm's scale vector into the weights of the
     # projection behind it at load time, which lets 1-2 row decode batches run (residual add +
     # norm + projection) as one kernel (csrc/skinny_norm_gemm.hip).  Measured on Qwen3-8B: 3.93

@@ -43,6 +43,12 @@ using namespace mvl;
 
 namespace {
 
+#ifndef MVL_BIG_ABLATE
+#define MVL_BIG_ABLATE 0     // measurement builds only; bits: 1 no fragment reads in the loop,
+#endif                       // 2 no DMA requests in the loop, 4 no barriers in the loop
+#ifndef MVL_BIG_STAMP
+#define MVL_BIG_STAMP 0      // measurement builds only: clock stamps of one K-tile's phases
+#endif                       // (waves 0 and 4 of workgroup 0) overwrite the start of `out`
 constexpr int kBigThreads = 512;
 constexpr int kHalf = 128 * 128;            // bytes of a half-tile
 constexpr int kBuf = 4 * kHalf;             // one K-tile: A0 B0 B1 A1
@@ -67,6 +73,7 @@ __device__ __forceinline__ void big_wait_vmcnt() {
 }
 
 __device__ __forceinline__ void big_barrier() {
+    if (MVL_BIG_ABLATE & 4) { __builtin_amdgcn_sched_barrier(0); return; }
     __builtin_amdgcn_sched_barrier(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -145,6 +152,7 @@ void big_gemm_kernel(BigArgs a) {
         constexpr int J = decltype(j_c)::value;
         constexpr bool is_a = (J == 0 || J == 3);
         constexpr int h = (J == 2 || J == 3) ? 1 : 0;
+        if (MVL_BIG_ABLATE & 2) return;
         char* dst = smem + bofs + J * kHalf + wv * 2048;
         const long kb = (long)k * (kBigBK * 2);
 #pragma unroll
@@ -163,8 +171,15 @@ void big_gemm_kernel(BigArgs a) {
 
     f32x4_t acc[4][2][4];                    // [quadrant TL TR BR BL][W block][x block]
     vec8 af[2][4], bl[2][2], br[2][2];       // [k half][block]
+    if (MVL_BIG_ABLATE & 1) {
+        for (int ks = 0; ks < 2; ++ks) {
+            for (int m = 0; m < 4; ++m) af[ks][m] = __builtin_bit_cast(vec8, u32x4_t{(uint32_t)lane, 1u, 2u, 3u});
+            for (int n = 0; n < 2; ++n) { bl[ks][n] = af[ks][n]; br[ks][n] = af[ks][n + 2]; }
+        }
+    }
 
     auto read_a = [&](int bofs, auto j_c) {
+        if (MVL_BIG_ABLATE & 1) return;
         constexpr int J = decltype(j_c)::value;
         const char* base = smem + bofs + J * kHalf;
 #pragma unroll
@@ -175,6 +190,7 @@ void big_gemm_kernel(BigArgs a) {
                     vec8, *reinterpret_cast<const u32x4_t*>(base + m * 2048 + (a_off ^ (ks << 6))));
     };
     auto read_b = [&](int bofs, auto j_c, vec8 (&bf)[2][2]) {
+        if (MVL_BIG_ABLATE & 1) return;
         constexpr int J = decltype(j_c)::value;
         const char* base = smem + bofs + J * kHalf;
 #pragma unroll
@@ -186,7 +202,6 @@ void big_gemm_kernel(BigArgs a) {
     };
     auto mfma_quadrant = [&](auto q_c, vec8 (&bf)[2][2]) {
         constexpr int Q = decltype(q_c)::value;
-        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -194,7 +209,6 @@ void big_gemm_kernel(BigArgs a) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m)
                     acc[Q][n][m] = DT::mfma16(bf[ks][n], af[ks][m], acc[Q][n][m]);
-        __builtin_amdgcn_s_setprio(0);
     };
 
     using I0 = std::integral_constant<int, 0>;
@@ -211,37 +225,55 @@ void big_gemm_kernel(BigArgs a) {
     // FIRST: the tile's first K-tile.  Every earlier request was waited for before the previous
     // tile's epilogue, so this K-tile waits for nothing: the first counted wait after the
     // epilogue's stores (which it would force to complete) comes a whole K-tile later.
+    uint64_t stamps[16];
+#define MVL_STAMP(i) do { if (MVL_BIG_STAMP) stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
     auto ktile = [&](auto first_c, int g, int u, int nk) {
         constexpr bool FIRST = decltype(first_c)::value != 0;
         const int B = (g & 1) * kBuf, NB = kBuf - B;
         const bool n1 = u + 1 >= nk, n2 = u + 2 >= nk;
         const int k1 = n1 ? u + 1 - nk : u + 1, k2 = n2 ? u + 2 - nk : u + 2;
         // phase 1: (top, left)
+        MVL_STAMP(0);
         read_b(B, I1{}, bl);
         read_a(B, I0{});
         stage(NB, I2{}, n1, k1);
         if (!FIRST) big_wait_vmcnt<8>();
+        MVL_STAMP(1);
         big_barrier();
+        MVL_STAMP(2);
         mfma_quadrant(I0{}, bl);
+        MVL_STAMP(3);
         big_barrier();
         // phase 2: (top, right)
+        MVL_STAMP(4);
         read_b(B, I2{}, br);
         stage(NB, I3{}, n1, k1);
         if (!FIRST) big_wait_vmcnt<8>();
+        MVL_STAMP(5);
         big_barrier();
+        MVL_STAMP(6);
         mfma_quadrant(I1{}, br);
+        MVL_STAMP(7);
         big_barrier();
         // phase 3: (bottom, right)
+        MVL_STAMP(8);
         read_a(B, I3{});
         stage(B, I0{}, n2, k2);
+        MVL_STAMP(9);
         big_barrier();
+        MVL_STAMP(10);
         mfma_quadrant(I2{}, br);
+        MVL_STAMP(11);
         big_barrier();
         // phase 4: (bottom, left), no reads
+        MVL_STAMP(12);
         stage(B, I1{}, n2, k2);
         if (!FIRST) big_wait_vmcnt<8>();
+        MVL_STAMP(13);
         big_barrier();
+        MVL_STAMP(14);
         mfma_quadrant(I3{}, bl);
+        MVL_STAMP(15);
         big_barrier();
     };
 
@@ -381,6 +413,12 @@ void big_gemm_kernel(BigArgs a) {
     }
     if (wr == 0) big_barrier();
     big_wait_vmcnt<0>();
+    if (MVL_BIG_STAMP && bid == 0 && (wv & 3) == 0 && lane < 16) {
+        uint64_t v = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) v = lane == i ? stamps[i] : v;
+        reinterpret_cast<uint64_t*>(a.out)[wv * 4 + lane] = v;       // wave 0: slots 0..15, wave 4: 16..31
+    }
 }
 
 template <int CODE, bool SWI>

@@ -178,6 +178,8 @@ class ModelRunner:
             self.warmup_model()
             if self.on_gpu and cfg.tune_decode_gemms:
                 self._tune_decode_gemms()
+            if self.on_gpu and cfg.tune_prefill_gemms:
+                self._tune_prefill_gemms()
             self.allocate_kv_cache()
             if self.on_gpu and not self.enforce_eager:
                 self._capture_graphs_or_fall_back()
@@ -228,6 +230,26 @@ class ModelRunner:
                   f"{self.decode_gemm_choices}", flush=True)
             print(f"[runner] mid-batch GEMM choices (rows: library us, kernel us, (bn, splits, "
                   f"nt)): {self.mid_gemm_choices}", flush=True)
+
+    def _tune_prefill_gemms(self) -> None:
+        """Per projection and row bucket of a prefill step: the 256 x 256-tile kernel (gate_up:
+        with the SwiGLU epilogue, which saves the activation kernel's pass over the [T, 2I]
+        intermediate) or the library GEMM, decided by timing both on this model's weights."""
+        from minivllm_amd.ops import hip
+        layers = list(self.model.model.layers)[:4]
+        roles = {"qkv": ([l.self_attn.qkv_proj.weight for l in layers], False),
+                 "o": ([l.self_attn.o_proj.weight for l in layers], False),
+                 "gate_up": ([l.mlp.gate_up_proj.weight for l in layers], True),
+                 "down": ([l.mlp.down_proj.weight for l in layers], False)}
+        top = max(self.cfg.max_num_batched_tokens, 512)
+        rows = [b for b in hip.BIG_ROW_BUCKETS if b // 2 < top]
+        self.prefill_gemm_choices = {name: hip.tune_big_gemm(ws, swiglu, rows=rows)
+                                     for name, (ws, swiglu) in roles.items()}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        if self.rank == 0 and self.cfg.log_stats:
+            print(f"[runner] prefill GEMM choices (rows: library us, kernel us, use kernel): "
+                  f"{self.prefill_gemm_choices}", flush=True)
 
     # ================================================================ buffers
     def _init_buffers(self) -> None:

@@ -97,9 +97,9 @@ def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scal
 
 
 def linear(x, weight, bias=None, to_norm=False):
-    """``x @ weight.T (+ bias)``: the library GEMM, except for decode-sized GPU inputs (<= 16
-    rows: skinny kernel; 17..256 rows: mid-batch kernel) of the shapes where the hand-written
-    weight-streaming kernels were measured to be faster on this machine.  ``to_norm``: the
+    """``x @ weight.T (+ bias)``: the library GEMM, except for the GPU inputs (<= 16 rows: skinny
+    kernel; 17..256 rows: mid-batch kernel; more: the 256 x 256-tile prefill kernel) of the
+    shapes where the hand-written kernels were measured to be faster on this machine.  ``to_norm``: the
     caller passes the result straight to ``norm_linear`` / ``add_rms_norm`` (and to nothing
     else), which lets a K-split mid-batch GEMM hand over its unsummed slices
     (``hip.SplitKPartials``) for the norm kernel to sum."""
@@ -115,12 +115,16 @@ def linear(x, weight, bias=None, to_norm=False):
             c = h.mid_gemm_choice(x, weight, to_norm=to_norm)
             if c is not None:
                 return h.mid_linear(x, weight, bias, False, c[0], c[1], c[2], defer=to_norm)
+    elif _on_gpu(x) and x.dim() == 2 and _hip().big_gemm_pays(x, weight):
+        return _hip().big_linear(x, weight, bias)
     return F.linear(x, weight, bias)
 
 
 def swiglu_linear(x, weight, bias=None):
-    """``silu(x @ Wg.T) * (x @ Wu.T)`` for the fused ``[Wg; Wu]`` weight: one kernel for
-    decode-sized GPU inputs, otherwise GEMM + activation kernel."""
+    """``silu(x @ Wg.T) * (x @ Wu.T)`` for the fused ``[Wg; Wu]`` weight: one kernel where the
+    start-up measurements preferred a hand-written one (decode-sized inputs: weight-streaming
+    kernels; prefill-sized: the 256 x 256-tile kernel with the SwiGLU epilogue), otherwise
+    GEMM + activation kernel."""
     if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 256:
         h = _hip()
         if x.shape[0] <= 16:
@@ -130,6 +134,8 @@ def swiglu_linear(x, weight, bias=None):
             c = h.mid_gemm_choice(x, weight, swiglu=True)
             if c is not None:
                 return h.mid_linear(x, weight, bias, True, c[0], c[1], c[2])
+    elif _on_gpu(x) and x.dim() == 2 and _hip().big_gemm_pays(x, weight, swiglu=True):
+        return _hip().big_linear(x, weight, bias, swiglu=True)     # prefill: GEMM + SwiGLU in one kernel
     return silu_and_mul(F.linear(x, weight, bias))
 
 

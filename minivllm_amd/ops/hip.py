@@ -905,7 +905,7 @@ BIG_MIN_ROWS = 257                    # below this the weight-streaming kernels 
 
 def big_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
     """Operands the 256 x 256-tile kernel can take: 2-D 16-bit row-major x (row stride a multiple
-    of 8 elements) and contiguous weights of the same dtype, K a multiple of 64 and >= 128, the
+    of 8 elements) and contiguous weights of the same dtype, K a multiple of 64 and >= 256, the
     output width (per SwiGLU half: N / 2) a multiple of 256 (128), operands below 4 GiB."""
     if x.dim() != 2 or weight.dim() != 2 or x.dtype not in _DT or weight.dtype != x.dtype:
         return False
@@ -913,14 +913,65 @@ def big_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> 
     N = weight.shape[0]
     if weight.shape[1] != K or not weight.is_contiguous() or x.stride(1) != 1 or x.stride(0) % 8:
         return False
-    if K % 64 or K < 128 or M < 1:
+    if K % 64 or K < 256 or M < 1:
         return False
     if swiglu:
         if N % 2 or (N // 2) % 128:
             return False
     elif N % 256:
         return False
-    return M * x.stride(0) * 2 < (1 << 32) and N * K * 2 < (1 << 32)
+    n_out = N // 2 if swiglu else N
+    return (M * x.stride(0) * 2 < (1 << 32) and N * K * 2 < (1 << 32)
+            and M * n_out * 2 < (1 << 31) and x.data_ptr() % 16 == 0)
+
+
+# (row bucket, N, K, swiglu) -> True where the kernel was measured faster than the library path;
+# filled by tune_big_gemm at start-up.  Unmeasured shapes go to the library.
+_BIG_CHOICE: dict = {}
+BIG_ROW_BUCKETS = (512, 1024, 2048, 4096, 8192, 16384)
+
+
+def big_row_bucket(m: int) -> int:
+    for b in BIG_ROW_BUCKETS:
+        if m <= b:
+            return b
+    return BIG_ROW_BUCKETS[-1]
+
+
+def big_gemm_pays(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
+    """True when this call should run on the 256 x 256-tile kernel: more than 256 rows, operands
+    the kernel takes, and a start-up measurement that preferred it for this shape."""
+    if x.dim() != 2 or x.shape[0] < BIG_MIN_ROWS:
+        return False
+    n, k = weight.shape
+    return bool(_BIG_CHOICE.get((big_row_bucket(x.shape[0]), n, k, swiglu))) \
+        and big_gemm_ok(x, weight, swiglu)
+
+
+def tune_big_gemm(weights, swiglu: bool = False, rows=BIG_ROW_BUCKETS, margin: float = 0.98) -> dict:
+    """For one projection (same-shaped matrices of a few layers): time the library GEMM
+    (+ activation kernel with ``swiglu``) against the 256 x 256-tile kernel at each row count
+    and record the winner under the row bucket.  Returns {rows: (library us, kernel us, use
+    kernel)}."""
+    import torch.nn.functional as F
+    weights = list(weights)[:4]
+    n, k = weights[0].shape
+    dtype, dev = weights[0].dtype, weights[0].device
+    out = {}
+    for m in rows:
+        x = torch.randn(m, k, dtype=dtype, device=dev)
+        if not big_gemm_ok(x, weights[0], swiglu):
+            return out
+        lib = (lambda xx, w: silu_and_mul(F.linear(xx, w))) if swiglu else (lambda xx, w: F.linear(xx, w))
+        ker = lambda xx, w: big_linear(xx, w, None, swiglu)
+        reps = max(1, min(8, int(2e11 / (2.0 * m * n * k))))
+        t_lib = _graph_time_ms(lib, x, weights, reps)
+        t_ker = _graph_time_ms(ker, x, weights, reps)
+        use = t_ker < t_lib * margin
+        _BIG_CHOICE[(big_row_bucket(m), n, k, swiglu)] = use
+        out[m] = (round(t_lib * 1e3, 1), round(t_ker * 1e3, 1), use)
+        del x
+    return out
 
 
 def big_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,

@@ -805,6 +805,99 @@ def test_ops_linear_to_norm_dispatch(hip):
         hip._MID_CHOICE.update(saved)
 
 
+# ------------------------------------------------------- prefill-sized GEMM (256 x 256 tiles)
+def _big_check(hip, dtype, M, N, K, swiglu=False, bias=False, strided=False, out_strided=False):
+    torch.manual_seed(37)
+    if strided:
+        x = torch.randn(M + 3, K + 64, device=DEV, dtype=dtype)[:M, :K]
+    else:
+        x = torch.randn(M, K, device=DEV, dtype=dtype)
+    w = (torch.randn(N, K, device=DEV) * 0.03).to(dtype)
+    b = torch.randn(N, device=DEV, dtype=dtype) if bias else None
+    y = x.float() @ w.float().T
+    if bias:
+        y = y + b.float()
+    want = torch.nn.functional.silu(y[:, :N // 2]) * y[:, N // 2:] if swiglu else y
+    n_out = want.shape[1]
+    if out_strided:
+        buf = torch.full((M + 2, n_out + 72), 7.0, device=DEV, dtype=dtype)
+        got = hip.big_linear(x, w, b, swiglu, out=buf[:M, :n_out])
+        assert got.data_ptr() == buf.data_ptr()
+        assert bool((buf[M:] == 7).all()) and bool((buf[:, n_out:] == 7).all()), "wrote outside its view"
+    else:
+        guard = torch.full((M + 1, n_out), 7.0, device=DEV, dtype=dtype)
+        got = hip.big_linear(x, w, b, swiglu, out=guard[:M])
+        assert bool((guard[M] == 7).all()), "wrote a row beyond M"
+    assert got.shape == want.shape
+    close(got, want, dtype, 4)
+
+
+# (N, K) of the projections of Qwen3-0.6B / 8B / 32B and of the per-rank shapes at TP = 8 that the
+# kernel can take (N a multiple of 256)
+_BIG_SHAPES = [(4096, 1024), (1024, 2048), (1024, 3072), (6144, 4096), (4096, 4096), (4096, 12288),
+               (10240, 5120), (5120, 8192), (768, 4096), (4096, 512), (4096, 1536), (1280, 5120),
+               (5120, 3200)]
+
+
+@pytest.mark.parametrize("M", [257, 1000, 2048])
+@pytest.mark.parametrize("N,K", _BIG_SHAPES)
+def test_big_gemm_shapes(hip, M, N, K):
+    """Projection shapes x row counts (one below a tile edge, one inside a tile, whole tiles) vs
+    the fp32 product."""
+    if K % 64:
+        pytest.skip("K must be a multiple of 64")
+    _big_check(hip, torch.bfloat16, M, N, K)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [300, 512, 1111])
+@pytest.mark.parametrize("I,K", [(3072, 1024), (12288, 4096), (1536, 4096), (3200, 5120), (128, 256)])
+def test_big_gemm_swiglu(hip, dtype, M, I, K):
+    """Fused [gate; up] weight -> silu(gate) * up in the epilogue (3200 = 25 x 128: the Qwen3-32B
+    intermediate size per TP=8 rank), with bias on one row count."""
+    _big_check(hip, dtype, M, 2 * I, K, swiglu=True, bias=(M == 512))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("swiglu", [False, True])
+def test_big_gemm_views(hip, dtype, swiglu):
+    """Strided activations, an output view inside a wider buffer, bias."""
+    _big_check(hip, dtype, 700, 1024, 512, swiglu=swiglu, bias=True, strided=True, out_strided=True)
+
+
+def test_big_gemm_many_tiles_per_workgroup(hip):
+    """More tiles than CUs (each workgroup walks several tiles: the half-tile pipeline crosses
+    tile boundaries and the last round is partly empty), odd and even K-tile counts."""
+    for M, N, K in ((4096 + 64, 8192, 256), (3000, 6144, 320), (8192, 2560, 448)):
+        _big_check(hip, torch.bfloat16, M, N, K)
+    _big_check(hip, torch.bfloat16, 5000, 2 * 4096, 384, swiglu=True)
+
+
+def test_big_gemm_k_structure(hip):
+    """Exact small-integer data: every k position of every row and column must land in the right
+    accumulator, and every output element in the right place."""
+    M, N, K = 777, 768, 512
+    x = torch.randint(-2, 3, (M, K), device=DEV).to(torch.bfloat16)
+    w = torch.randint(-2, 3, (N, K), device=DEV).to(torch.bfloat16)
+    w[::3] *= 2
+    x[:, ::5] *= 2
+    want = x.float() @ w.float().T
+    got = hip.big_linear(x, w)
+    assert torch.equal(got.float(), want.to(torch.bfloat16).float())
+
+
+def test_big_gemm_rejects(hip):
+    w = torch.zeros(1024, 1024, device=DEV, dtype=torch.bfloat16)
+    x = torch.zeros(512, 1024, device=DEV, dtype=torch.bfloat16)
+    assert hip.big_gemm_ok(x, w) and hip.big_gemm_ok(x, w, swiglu=True)
+    assert not hip.big_gemm_ok(x, w[:1000])                         # N not a multiple of 256
+    assert not hip.big_gemm_ok(x[:, :192].contiguous(), w[:, :192].contiguous())   # K < 256 ... or not a multiple of 64
+    assert not hip.big_gemm_ok(x.float(), w.float())
+    assert not hip.big_gemm_pays(x, w)                              # nothing measured: library
+    with pytest.raises(ValueError):
+        hip.big_linear(x, w[:1000])
+
+
 def test_mid_gemm_rejects(hip):
     w = torch.zeros(1024, 1000, device=DEV, dtype=torch.bfloat16)
     assert not hip.mid_gemm_ok(torch.zeros(64, 1000, device=DEV, dtype=torch.bfloat16), w)
