@@ -61,6 +61,7 @@ struct BigArgs {
     const uint16_t* bias;                   // may be null
     uint16_t* out; long o_stride;
     unsigned out_bytes;                     // extent of `out` for the store range check
+    unsigned x_bytes, w_bytes;              // extents of x and W (buffer descriptors)
     int M, N, K;
     int up_off;                             // SwiGLU: row of W where the up projection starts
     int tiles_m, tiles_n, tiles, ktiles;
@@ -141,8 +142,10 @@ void big_gemm_kernel(BigArgs a) {
                 s.b[h][i] = (uint32_t)wrow * (uint32_t)(a.K * 2) + pchunk * 16;
             }
     };
-    const char* xk = reinterpret_cast<const char*>(a.x);
-    const char* wk = reinterpret_cast<const char*>(a.w);
+    const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t*>(a.w), 0, (int)a.w_bytes, 0x00020000);
 
     // request half-tile J (0 A0, 1 B0, 2 B1, 3 A1) of K-tile k of this workgroup's current tile
     // (or, with `next`, of its next tile) into the buffer at LDS byte offset bofs; bofs, k and
@@ -154,12 +157,16 @@ void big_gemm_kernel(BigArgs a) {
         constexpr int h = (J == 2 || J == 3) ? 1 : 0;
         if (MVL_BIG_ABLATE & 2) return;
         char* dst = smem + bofs + J * kHalf + wv * 2048;
-        const long kb = (long)k * (kBigBK * 2);
+        const int kb = k * (kBigBK * 2);                 // uniform byte offset along K
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const uint32_t off = is_a ? (next ? nxt.a[h][i] : cur.a[h][i])
                                       : (next ? nxt.b[h][i] : cur.b[h][i]);
-            glds16((is_a ? xk : wk) + kb + off, dst + i * 1024);
+            // buffer form of the LDS-DMA: per-lane offset in a VGPR, the K offset in an SGPR,
+            // no address arithmetic on the vector ALU
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(is_a ? xrsrc : wrsrc,
+                                                 (__attribute__((address_space(3))) void*)(dst + i * 1024),
+                                                 16, (int)off, kb, 0, 0);
         }
     };
 
@@ -453,13 +460,15 @@ extern "C" int mvl_big_gemm(const void* x, long x_stride, const void* w, const v
     if (x_stride % 8 != 0 || o_stride % 8 != 0) return -1;
     const int n_out = swiglu ? N / 2 : N;
     const double out_bytes = ((double)(M - 1) * (double)o_stride + n_out) * 2.0;
-    if ((double)M * (double)x_stride * 2.0 >= 4294967296.0 || (double)N * (double)K * 2.0 >= 4294967296.0
+    if ((double)M * (double)x_stride * 2.0 >= 2147483648.0 || (double)N * (double)K * 2.0 >= 2147483648.0
         || out_bytes >= 2147483648.0)
         return -1;
     BigArgs a;
     a.x = (const uint16_t*)x; a.x_stride = x_stride; a.w = (const uint16_t*)w;
     a.bias = (const uint16_t*)bias; a.out = (uint16_t*)out; a.o_stride = o_stride;
     a.out_bytes = (unsigned)out_bytes;
+    a.x_bytes = (unsigned)(((double)(M - 1) * (double)x_stride + K) * 2.0);
+    a.w_bytes = (unsigned)((double)N * (double)K * 2.0);
     a.M = M; a.N = N; a.K = K; a.up_off = N / 2;
     a.tiles_m = (M + 255) / 256;
     a.tiles_n = swiglu ? (N / 2) / 128 : N / 256;
