@@ -290,7 +290,8 @@ class NativeBlockManager:
 
     def allocate(self, seq: Sequence) -> None:
         assert not seq.block_table, "sequence already has blocks"
-        toks = np.ascontiguousarray(seq.token_ids, dtype=np.int32)
+        # the sequence's cached int32 image (no list -> array conversion per admission)
+        toks = np.ascontiguousarray(seq.token_array(0, seq.num_tokens))
         table = np.empty(seq.num_blocks, dtype=np.int32)
         cached = self._lib.mvl_bm_allocate(self._h, toks.ctypes.data, len(toks), table.ctypes.data)
         if cached < 0:

@@ -487,35 +487,41 @@ class ModelRunner:
         with one decode token each (mixed step); their row is the newest token, whose key is
         everything before it in the paged cache."""
         bs = self.block_size
-        ids, pos, slots, cu_q, cu_k = [], [], [], [0], [0]
-        max_q = max_k = max_ctx = 0
-        has_prefix = num_decode > 0
-        first_decode = len(seqs) - num_decode
+        B = len(seqs)
+        first_decode = B - num_decode
+        starts = np.empty(B, np.int64)
+        ends = np.empty(B, np.int64)
+        ids = []
         for i, seq in enumerate(seqs):
             if i >= first_decode:
-                start, end = seq.num_tokens - 1, seq.num_tokens
-                max_ctx = max(max_ctx, end)
+                starts[i], ends[i] = seq.num_tokens - 1, seq.num_tokens
             else:
-                start = seq.num_cached_tokens
-                end = seq.num_tokens if seq.prefill_end is None else seq.prefill_end
-                max_q = max(max_q, end - start)
-            has_prefix |= start > 0
-            p = np.arange(start, end, dtype=np.int32)
-            bt = np.asarray(seq.block_table, dtype=np.int32)
-            ids.append(np.asarray(seq.token_ids[start:end], dtype=np.int32))
-            pos.append(p)
-            slots.append(bt[p // bs] * bs + p % bs)
-            cu_q.append(cu_q[-1] + end - start)
-            cu_k.append(cu_k[-1] + end)
-            max_k = max(max_k, end)
-        B = len(seqs)
-        MB = max(len(s.block_table) for s in seqs)
-        tables = np.full((B, MB), -1, np.int32)
-        for i, s in enumerate(seqs):
-            tables[i, :len(s.block_table)] = s.block_table
-        input_ids = np.concatenate(ids)
-        positions = np.concatenate(pos)
-        slot_mapping = np.concatenate(slots).astype(np.int32)
+                starts[i] = seq.num_cached_tokens
+                ends[i] = seq.num_tokens if seq.prefill_end is None else seq.prefill_end
+            ids.append(seq.token_array(int(starts[i]), int(ends[i])))
+        lens = ends - starts
+        max_q = int(lens[:first_decode].max()) if first_decode else 0
+        max_ctx = int(ends[first_decode:].max()) if num_decode else 0
+        max_k = int(ends.max())
+        has_prefix = num_decode > 0 or bool(starts.any())
+        cu_q = np.zeros(B + 1, np.int64)
+        cu_k = np.zeros(B + 1, np.int64)
+        np.cumsum(lens, out=cu_q[1:])
+        np.cumsum(ends, out=cu_k[1:])
+        total = int(cu_q[-1])
+        # one pass over all rows, in int32: row i of sequence b is token starts[b] + (i - cu_q[b])
+        row = np.repeat(np.arange(B, dtype=np.int32), lens)
+        positions = np.arange(total, dtype=np.int32) - np.repeat((cu_q[:-1] - starts).astype(np.int32), lens)
+        tables = _pad_block_tables([s.block_table for s in seqs])
+        if bs & (bs - 1) == 0:
+            sh = bs.bit_length() - 1
+            blk, off = positions >> sh, positions & (bs - 1)
+        else:
+            blk, off = positions // bs, positions % bs
+        slot_mapping = tables.reshape(-1).take(row * np.int32(tables.shape[1]) + blk)
+        slot_mapping *= np.int32(bs)
+        slot_mapping += off
+        input_ids = np.concatenate(ids) if B > 1 else np.array(ids[0], dtype=np.int32)
         num_prefill_tokens = int(input_ids.size) - num_decode
         pad = prefill_token_bucket(input_ids.size) - input_ids.size if self.on_gpu else 0
         if pad:
@@ -525,8 +531,8 @@ class ModelRunner:
             positions = np.concatenate([positions, np.zeros(pad, np.int32)])
             slot_mapping = np.concatenate([slot_mapping, np.full(pad, -1, np.int32)])
         arrays = dict(input_ids=input_ids, positions=positions, slot_mapping=slot_mapping,
-                      cu_seqlens_q=np.asarray(cu_q, np.int32),
-                      cu_seqlens_k=np.asarray(cu_k, np.int32),
+                      cu_seqlens_q=cu_q.astype(np.int32),
+                      cu_seqlens_k=cu_k.astype(np.int32),
                       temperatures=np.asarray([s.temperature for s in seqs], np.float32),
                       block_tables=tables)
         if num_decode:
