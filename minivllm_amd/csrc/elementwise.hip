@@ -192,7 +192,8 @@ __global__ void qk_norm_rope_store_kernel(
         const float* __restrict__ cos_sin, const uint16_t* __restrict__ qw,
         const uint16_t* __restrict__ kw, float eps, int Hq, int Hkv,
         uint16_t* k_cache, uint16_t* v_cache, long c_stride_b, long c_stride_t, long c_stride_h,
-        int block_size, const int* __restrict__ slot_mapping, long total_rows, int first_head) {
+        int block_size, const int* __restrict__ slot_mapping, long total_rows, int first_head,
+        int write_back) {
     constexpr int LPR = D / 8;
     constexpr int RPW = 64 / LPR;                // rows per wave
     const int lane = threadIdx.x & 63;
@@ -246,8 +247,12 @@ __global__ void qk_norm_rope_store_kernel(
         }
         a[0] = pack2<CODE>(x1[0], x1[1]); a[1] = pack2<CODE>(x1[2], x1[3]);
         b[0] = pack2<CODE>(x2[0], x2[1]); b[1] = pack2<CODE>(x2[2], x2[3]);
-        *reinterpret_cast<u32x2_t*>(p + 4 * j) = a;
-        *reinterpret_cast<u32x2_t*>(p + D / 2 + 4 * j) = b;
+        // write_back == 0: the transformed K rows are only needed in the cache (the attention
+        // kernel of this step reads them from there), so the pass over qkv is read-only
+        if (write_back || !is_k) {
+            *reinterpret_cast<u32x2_t*>(p + 4 * j) = a;
+            *reinterpret_cast<u32x2_t*>(p + D / 2 + 4 * j) = b;
+        }
     }
     if (active && (is_k || is_v) && k_cache != nullptr && slot_mapping != nullptr) {
         const int slot = slot_mapping[t];
@@ -275,7 +280,8 @@ extern "C" int mvl_qk_norm_rope_store(void* qkv, long qkv_stride, const int* pos
                                       float eps, long T, int Hq, int Hkv, int D, void* k_cache,
                                       void* v_cache, long c_stride_b, long c_stride_t,
                                       long c_stride_h, int block_size, const int* slot_mapping,
-                                      int dtype, int kv_fp8, int skip_q, void* stream) {
+                                      int dtype, int kv_fp8, int skip_q, int write_back,
+                                      void* stream) {
     if (D != 64 && D != 128) return -1;
     if (T == 0) return 0;
     const int first_head = skip_q ? Hq : 0;
@@ -289,7 +295,7 @@ extern "C" int mvl_qk_norm_rope_store(void* qkv, long qkv_stride, const int* pos
     qk_norm_rope_store_kernel<CODE, DD, K8><<<(unsigned)blocks, threads, 0, st>>>(             \
         (uint16_t*)qkv, qkv_stride, positions, cos_sin, (const uint16_t*)qw,                   \
         (const uint16_t*)kw, eps, Hq, Hkv, (uint16_t*)k_cache, (uint16_t*)v_cache, c_stride_b, \
-        c_stride_t, c_stride_h, block_size, slot_mapping, rows, first_head)
+        c_stride_t, c_stride_h, block_size, slot_mapping, rows, first_head, write_back)
     if (kv_fp8) {
         if (dtype == 0) { if (D == 128) MVL_LAUNCH_ROPE(0, 128, true); else MVL_LAUNCH_ROPE(0, 64, true); }
         else            { if (D == 128) MVL_LAUNCH_ROPE(1, 128, true); else MVL_LAUNCH_ROPE(1, 64, true); }

@@ -83,6 +83,12 @@ class Attention(nn.Module):
         through the decode kernel, which expects finished queries."""
         return bool(_FUSE_Q_ROPE and ctx.is_prefill and not ctx.num_decode_seqs and q.is_cuda)
 
+    def reads_k_from_cache(self, ctx) -> bool:
+        """True for prefill steps whose attention goes through the block table of a 16-bit cache
+        (the freshly projected ``k`` / ``v`` arguments of ``forward`` are then never read)."""
+        return bool(ctx.is_prefill and self.k_cache is not None and ctx.block_tables is not None
+                    and ctx.slot_mapping is not None and self.k_cache.dtype != torch.float8_e4m3fn)
+
     def forward(self, q: torch.Tensor, k: Optional[torch.Tensor] = None,
                 v: Optional[torch.Tensor] = None, q_rope=None) -> torch.Tensor:
         """q [T,Hq,D] (rows may be strided); k/v [T,Hkv,D] are only read when no cache

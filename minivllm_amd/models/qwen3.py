@@ -76,11 +76,15 @@ class Qwen3Attention(nn.Module):
         # pure prefill steps on the GPU: the store kernel handles K and V only and the
         # attention kernel norms and rotates its Q rows while loading them
         fuse = self.attn.fuses_q_rope(ctx, qkv)
+        # ... and when it reads K through the block table, the transformed K rows are needed in
+        # the cache only
+        k_in_place = not (fuse and self.attn.reads_k_from_cache(ctx))
         q, k, v = ops.qk_norm_rope_store(
             qkv, positions, cos_sin, q_weight,
             self.k_norm.weight if self.use_qk_norm else None,
             self.eps, self.num_heads, self.num_kv_heads, self.head_dim,
-            self.attn.k_cache, self.attn.v_cache, ctx.slot_mapping, skip_q=fuse)
+            self.attn.k_cache, self.attn.v_cache, ctx.slot_mapping, skip_q=fuse,
+            k_in_place=k_in_place)
         o = self.attn(q, k, v, q_rope=(positions, cos_sin, q_weight, self.eps) if fuse else None)
         return self.o_proj(o, defer_reduce=defer_reduce)
 

@@ -43,12 +43,17 @@ def silu_and_mul(x):
 
 
 def qk_norm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, num_heads, num_kv_heads,
-                       head_dim, k_cache, v_cache, slot_mapping, skip_q=False):
+                       head_dim, k_cache, v_cache, slot_mapping, skip_q=False, k_in_place=True):
     """``skip_q``: leave the Q rows as projected; the prefill attention call that follows is
-    then given ``q_rope`` and transforms them while loading (one pass over Q less)."""
-    f = _hip().qk_norm_rope_store if _on_gpu(qkv) else torch_ref.qk_norm_rope_store
-    return f(qkv, positions, cos_sin, q_weight, k_weight, eps, num_heads, num_kv_heads, head_dim,
-             k_cache, v_cache, slot_mapping, skip_q)
+    then given ``q_rope`` and transforms them while loading (one pass over Q less).
+    ``k_in_place=False``: the caller reads K from the cache only, so the GPU kernel does not
+    write the transformed K rows back into ``qkv`` (the CPU path always does)."""
+    if _on_gpu(qkv):
+        return _hip().qk_norm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, num_heads,
+                                         num_kv_heads, head_dim, k_cache, v_cache, slot_mapping,
+                                         skip_q, k_in_place)
+    return torch_ref.qk_norm_rope_store(qkv, positions, cos_sin, q_weight, k_weight, eps, num_heads,
+                                        num_kv_heads, head_dim, k_cache, v_cache, slot_mapping, skip_q)
 
 
 def store_kvcache(key, value, k_cache, v_cache, slot_mapping):

@@ -42,7 +42,7 @@ _silu = _sig("mvl_silu_and_mul", _c_void, _c_void, _c_long, _c_int, _c_long, _c_
              _c_void)
 _rope = _sig("mvl_qk_norm_rope_store", _c_void, _c_long, _c_void, _c_void, _c_void, _c_void,
              _c_float, _c_long, _c_int, _c_int, _c_int, _c_void, _c_void, _c_long, _c_long,
-             _c_long, _c_int, _c_void, _c_int, _c_int, _c_int, _c_void)
+             _c_long, _c_int, _c_void, _c_int, _c_int, _c_int, _c_int, _c_void)
 _gather_widen = _sig("mvl_kv_gather_widen", _c_void, _c_void, _c_long, _c_long, _c_long, _c_int,
                      _c_void, _c_int, _c_void, _c_void, _c_void, _c_int, _c_int, _c_int, _c_int,
                      _c_int, _c_void)
@@ -175,10 +175,13 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
                        q_weight: Optional[torch.Tensor], k_weight: Optional[torch.Tensor],
                        eps: float, num_heads: int, num_kv_heads: int, head_dim: int,
                        k_cache: Optional[torch.Tensor], v_cache: Optional[torch.Tensor],
-                       slot_mapping: Optional[torch.Tensor], skip_q: bool = False):
+                       slot_mapping: Optional[torch.Tensor], skip_q: bool = False,
+                       k_in_place: bool = True):
     """Works in place on ``qkv`` [T, (Hq+2Hkv)*D]; returns (q, k, v) views of it.  ``skip_q``:
     the Q rows are left as projected (the prefill attention kernel transforms them itself when
-    it is handed ``q_rope``)."""
+    it is handed ``q_rope``).  ``k_in_place=False`` (needs a cache): the transformed K rows go to
+    the cache only and the K rows of ``qkv`` keep the raw projection (for steps whose attention
+    reads K from the cache)."""
     assert qkv.dim() == 2 and qkv.stride(1) == 1
     T = qkv.shape[0]
     qs, ks = num_heads * head_dim, num_kv_heads * head_dim
@@ -204,7 +207,8 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
                  k_cache.data_ptr() if have_cache else None,
                  v_cache.data_ptr() if have_cache else None, sb, st, sh, bs,
                  slot_mapping.data_ptr() if have_cache else None, _dt(qkv),
-                 _kv_fp8(k_cache) if have_cache else 0, int(skip_q), _stream()),
+                 _kv_fp8(k_cache) if have_cache else 0, int(skip_q),
+                 int(k_in_place or not have_cache), _stream()),
            "qk_norm_rope_store")
     q = qkv[:, :qs].view(T, num_heads, head_dim)
     k = qkv[:, qs:qs + ks].view(T, num_kv_heads, head_dim)

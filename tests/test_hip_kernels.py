@@ -97,6 +97,13 @@ def test_qk_norm_rope_store(hip, dtype, d, with_norm):
     close(v_h, v_r, dtype)
     close(kc_h, kc_r, dtype, 2)
     close(vc_h, vc_r, dtype)
+    # prefill form: Q rows untouched, K transformed into the cache only (qkv keeps the raw K rows)
+    kc_p, vc_p = _logical_cache(nb, bs, hkv, d, dtype), _logical_cache(nb, bs, hkv, d, dtype)
+    raw = qkv.clone()
+    hip.qk_norm_rope_store(raw, pos, cs, qw, kw, 1e-6, hq, hkv, d, kc_p, vc_p, slots, skip_q=True,
+                           k_in_place=False)
+    assert torch.equal(raw, qkv)
+    assert torch.equal(kc_p, kc_h) and torch.equal(vc_p, vc_h)
 
 
 @pytest.mark.parametrize("head_major", [True, False])
