@@ -23,6 +23,7 @@
 //    heads of one KV head and adjacent Q tiles of one sequence, heaviest Q tiles first.
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 using namespace mvl;
 
@@ -45,6 +46,8 @@ struct PrefillArgs {
     const int* block_tables; int bt_stride; int bs_log2;
     float scale_log2;
     int B, Hq, Hkv, n_qtiles;
+    int n_items;                               // Q-tile items per (sequence, head): n_qtiles, or pairs of them
+    int pair;                                  // 0: an item is one Q tile; g > 0: g pairs (n_qtiles - 1 - p, p)
     int total_wg;
     // optional: q holds the raw projection and the kernel applies the per-head RMSNorm (weight
     // q_w, may be null) and the rotary embedding (fp32 table [position][D]: cos of the D/2
@@ -88,22 +91,40 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     }
     const int G = a.Hq / a.Hkv;
     const int g = id % G;              id /= G;
-    const int qti = id % a.n_qtiles;   id /= a.n_qtiles;
+    const int qti = id % a.n_items;    id /= a.n_items;
     const int kvh = id % a.Hkv;
     const int b = id / a.Hkv;
     const int head = kvh * G + g;
 
     const int q_start = a.cu_q[b], q_len = a.cu_q[b + 1] - q_start;
     const int k_start = a.cu_k[b], k_len = a.cu_k[b + 1] - k_start;
-    const int qt = a.n_qtiles - 1 - qti;                 // heaviest tiles first
-    const int q0 = qt * kBM;
-    if (q0 >= q_len) return;                             // uniform for the workgroup
     const int pos_off = k_len - q_len;                   // query i sits at key position i + off
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r32 = lane & 31;
     const int hh = lane >> 5;
+
+    // A workgroup handles one Q tile, or (pair = g > 0) g heavy / light pairs of them in turn:
+    // under the causal mask tile i attends to i + 1 key blocks, so the pair (n - 1 - p, p) always
+    // costs n + 1 of them; every workgroup of a sequence then runs equally long and the fixed
+    // cost of a workgroup (launch, ramp-up, drain) is paid once per 2 g tiles.
+    const int n_pairs = (a.n_qtiles + 1) >> 1;
+    const int n_pass = a.pair ? 2 * a.pair : 1;
+#pragma unroll 1
+    for (int pass = 0; pass < n_pass; ++pass) {
+    int qt;
+    if (a.pair) {
+        const int p = qti * a.pair + (pass >> 1);
+        if (p >= n_pairs) break;
+        if ((pass & 1) && 2 * p == a.n_qtiles - 1) continue;     // the middle tile of an odd count: once
+        qt = (pass & 1) ? p : a.n_qtiles - 1 - p;
+    } else {
+        qt = a.n_qtiles - 1 - qti;                       // heaviest tiles first
+    }
+    const int q0 = qt * kBM;
+    if (q0 >= q_len) continue;                           // uniform for the workgroup
+    if (pass) __syncthreads();                           // every wave is done with the LDS tiles
 
     // ---- Q^T fragments: lane holds Q[row r32][16 s + 8 hh .. +7] ------------------------
     const int my_q = q0 + 32 * w + r32;                  // query index within the sequence
@@ -360,6 +381,7 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
                 *reinterpret_cast<u32x2_t*>(op + 32 * n + 8 * g8 + 4 * hh) = o;
             }
     }
+    }   // pass
 }
 
 template <int CODE, int D, bool PAGED>
@@ -396,7 +418,14 @@ extern "C" int mvl_flash_attention_prefill(
     a.scale_log2 = scale * kLog2e;
     a.B = B; a.Hq = Hq; a.Hkv = Hkv;
     a.n_qtiles = (max_q_len + kBM - 1) / kBM;
-    a.total_wg = B * Hq * a.n_qtiles;
+    static const char* pair_env = getenv("MVL_PREFILL_PAIR");
+    // pairs per workgroup: as many (1, 2 or 4) as still leave two workgroups per CU
+    int group = 4;
+    const int n_pairs = (a.n_qtiles + 1) / 2;
+    while (group > 1 && (long)B * Hq * ((n_pairs + group - 1) / group) < 512) group >>= 1;
+    a.pair = pair_env ? atoi(pair_env) : group;
+    a.n_items = a.pair ? (n_pairs + a.pair - 1) / a.pair : a.n_qtiles;
+    a.total_wg = B * Hq * a.n_items;
     if (cos_sin != nullptr && positions == nullptr) return -1;
     a.positions = positions; a.cos_sin = cos_sin; a.q_w = (const uint16_t*)q_w; a.eps = eps;
     auto st = (hipStream_t)stream;

@@ -48,6 +48,7 @@ int main(int argc, char** argv) {
     a.B = B; a.Hq = Hq; a.Hkv = Hkv;
     a.positions = nullptr; a.cos_sin = nullptr; a.q_w = nullptr; a.eps = 0.f;
     a.n_qtiles = (S + kBM - 1) / kBM;
+    a.pair = 0; a.n_items = a.n_qtiles;          // one Q tile per workgroup: the stamps are per tile count
     a.total_wg = B * Hq * a.n_qtiles;
     CK(hipMalloc(&probe, (size_t)a.total_wg * 8 * 8));
     CK(hipMemset(probe, 0, (size_t)a.total_wg * 8 * 8));
