@@ -100,11 +100,6 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     const int k_start = a.cu_k[b], k_len = a.cu_k[b + 1] - k_start;
     const int pos_off = k_len - q_len;                   // query i sits at key position i + off
 
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r32 = lane & 31;
-    const int hh = lane >> 5;
-
     // A workgroup handles one Q tile, or (pair = g > 0) g heavy / light pairs of them in turn:
     // under the causal mask tile i attends to i + 1 key blocks, so the pair (n - 1 - p, p) always
     // costs n + 1 of them; every workgroup of a sequence then runs equally long and the fixed
@@ -125,6 +120,14 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     const int q0 = qt * kBM;
     if (q0 >= q_len) continue;                           // uniform for the workgroup
     if (pass) __syncthreads();                           // every wave is done with the LDS tiles
+    // every per-lane constant is derived inside the pass from a value the compiler cannot see
+    // through: hoisted out of the loop they would stay live across it and spill
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r32 = lane & 31;
+    const int hh = lane >> 5;
 
     // ---- Q^T fragments: lane holds Q[row r32][16 s + 8 hh .. +7] ------------------------
     const int my_q = q0 + 32 * w + r32;                  // query index within the sequence
@@ -152,7 +155,7 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     int st_row[ITER], st_ch[ITER];
 #pragma unroll
     for (int i = 0; i < ITER; ++i) {
-        const int c = i * kThreads + threadIdx.x;       // linear 16-byte slot of the tile image
+        const int c = i * kThreads + tid;               // linear 16-byte slot of the tile image
         st_row[i] = c / CPR;
         const int pos = c % CPR;
         st_ch[i] = pos ^ ((((st_row[i] & 3) << 2) | ((st_row[i] >> 2) & 3)) & (CPR - 1));
