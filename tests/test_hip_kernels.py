@@ -893,6 +893,26 @@ def test_big_gemm_k_structure(hip):
     assert torch.equal(got.float(), want.to(torch.bfloat16).float())
 
 
+def test_big_gemm_is_deterministic_under_memory_load(hip):
+    """The kernel's accumulation order is fixed, so a run that differs from the first in a single
+    bit has read a half-tile before it landed (or overwritten one still in use).  Repeats two
+    shapes while a second stream keeps the memory system busy (tools/big_gemm_race_screen.py is
+    the long form)."""
+    torch.manual_seed(41)
+    src = torch.empty(1 << 26, dtype=torch.int32, device=DEV)
+    dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+    for M, N, K, swi in ((4096, 4096, 1024, False), (4096, 6144, 2048, True)):
+        x = torch.randn(M, K, device=DEV, dtype=torch.bfloat16)
+        w = (torch.randn(N, K, device=DEV) * 0.03).to(torch.bfloat16)
+        first = hip.big_linear(x, w, None, swi).clone()
+        for _ in range(25):
+            with torch.cuda.stream(side):
+                dst.copy_(src, non_blocking=True)
+            assert torch.equal(hip.big_linear(x, w, None, swi), first)
+    torch.cuda.synchronize()
+
+
 def test_big_gemm_rejects(hip):
     w = torch.zeros(1024, 1024, device=DEV, dtype=torch.bfloat16)
     x = torch.zeros(512, 1024, device=DEV, dtype=torch.bfloat16)
