@@ -173,8 +173,8 @@ extern "C" int mvl_silu_and_mul(const void* x, void* out, long rows, int inter, 
 
 // ========================================= fused q/k RMSNorm + RoPE + KV store
 // qkv: [T, (Hq + 2 Hkv) * D], updated in place for the q and k heads.  One head-row
-// (token, head) is handled by LPR = D/8 lanes; a lane holds elements [4j, 4j+4) of the first
-// half and the matching elements of the second half, so the NeoX rotation pairs
+// (token, head) is handled by LPR = D/16 lanes; a lane holds elements [8j, 8j+8) of the first
+// half and the matching elements of the second half (16-byte accesses), so the NeoX rotation pairs
 // (i, i + D/2) sit in the same lane.  k (after norm + rotation) and v rows are also
 // scattered to the paged cache at slot_mapping[t] (logical slot = block * block_size +
 // offset; the cache's physical layout is given by strides).
@@ -194,7 +194,9 @@ __global__ void qk_norm_rope_store_kernel(
         uint16_t* k_cache, uint16_t* v_cache, long c_stride_b, long c_stride_t, long c_stride_h,
         int block_size, const int* __restrict__ slot_mapping, long total_rows, int first_head,
         int write_back) {
-    constexpr int LPR = D / 8;
+    // 16-byte accesses: a lane holds elements [8j, 8j+8) of the first half of its row and the
+    // matching 8 of the second half
+    constexpr int LPR = D / 16;
     constexpr int RPW = 64 / LPR;                // rows per wave
     const int lane = threadIdx.x & 63;
     const int j = lane % LPR;
@@ -207,51 +209,51 @@ __global__ void qk_norm_rope_store_kernel(
     const long t = active ? row / H : 0;
     const int h = first_head + (active ? (int)(row - t * H) : 0);
     uint16_t* p = qkv + t * qkv_stride + (long)h * D;
-    u32x2_t a = {0, 0}, b = {0, 0};
+    u32x4_t a = {0, 0, 0, 0}, b = {0, 0, 0, 0};
     if (active) {
-        a = *reinterpret_cast<const u32x2_t*>(p + 4 * j);
-        b = *reinterpret_cast<const u32x2_t*>(p + D / 2 + 4 * j);
+        a = *reinterpret_cast<const u32x4_t*>(p + 8 * j);
+        b = *reinterpret_cast<const u32x4_t*>(p + D / 2 + 8 * j);
     }
     const bool is_v = h >= Hq + Hkv;
     const bool is_k = h >= Hq && !is_v;
-    float x1[4], x2[4];
-    unpack2<CODE>(a[0], x1[0], x1[1]); unpack2<CODE>(a[1], x1[2], x1[3]);
-    unpack2<CODE>(b[0], x2[0], x2[1]); unpack2<CODE>(b[1], x2[2], x2[3]);
+    float x1[8], x2[8];
+    unpack8<CODE>(a, x1);
+    unpack8<CODE>(b, x2);
     // every lane takes part in the shuffles; v rows just ignore the result
     float ss = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) ss += x1[i] * x1[i] + x2[i] * x2[i];
+    for (int i = 0; i < 8; ++i) ss += x1[i] * x1[i] + x2[i] * x2[i];
 #pragma unroll
     for (int o = LPR / 2; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     if (active && !is_v) {
         const uint16_t* w = is_k ? kw : qw;
         if (w != nullptr) {
             const float rstd = rsqrtf(ss / (float)D + eps);
-            const u32x2_t wa = *reinterpret_cast<const u32x2_t*>(w + 4 * j);
-            const u32x2_t wb = *reinterpret_cast<const u32x2_t*>(w + D / 2 + 4 * j);
-            float w1[4], w2[4];
-            unpack2<CODE>(wa[0], w1[0], w1[1]); unpack2<CODE>(wa[1], w1[2], w1[3]);
-            unpack2<CODE>(wb[0], w2[0], w2[1]); unpack2<CODE>(wb[1], w2[2], w2[3]);
+            float w1[8], w2[8];
+            unpack8<CODE>(*reinterpret_cast<const u32x4_t*>(w + 8 * j), w1);
+            unpack8<CODE>(*reinterpret_cast<const u32x4_t*>(w + D / 2 + 8 * j), w2);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) { x1[i] *= rstd * w1[i]; x2[i] *= rstd * w2[i]; }
+            for (int i = 0; i < 8; ++i) { x1[i] *= rstd * w1[i]; x2[i] *= rstd * w2[i]; }
         }
-        const int pos = positions[t];
-        const float4 c = *reinterpret_cast<const float4*>(cos_sin + (long)pos * D + 4 * j);
-        const float4 s = *reinterpret_cast<const float4*>(cos_sin + (long)pos * D + D / 2 + 4 * j);
-        const float cc[4] = {c.x, c.y, c.z, c.w}, sn[4] = {s.x, s.y, s.z, s.w};
+        const float* cs = cos_sin + (long)positions[t] * D;
+        const f32x4_t c0 = *reinterpret_cast<const f32x4_t*>(cs + 8 * j);
+        const f32x4_t c1 = *reinterpret_cast<const f32x4_t*>(cs + 8 * j + 4);
+        const f32x4_t s0 = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 8 * j);
+        const f32x4_t s1 = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 8 * j + 4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float o1 = x1[i] * cc[i] - x2[i] * sn[i];
-            const float o2 = x1[i] * sn[i] + x2[i] * cc[i];
+        for (int i = 0; i < 8; ++i) {
+            const float cc = i < 4 ? c0[i & 3] : c1[i & 3], sn = i < 4 ? s0[i & 3] : s1[i & 3];
+            const float o1 = x1[i] * cc - x2[i] * sn;
+            const float o2 = x1[i] * sn + x2[i] * cc;
             x1[i] = o1; x2[i] = o2;
         }
-        a[0] = pack2<CODE>(x1[0], x1[1]); a[1] = pack2<CODE>(x1[2], x1[3]);
-        b[0] = pack2<CODE>(x2[0], x2[1]); b[1] = pack2<CODE>(x2[2], x2[3]);
+        a = pack8<CODE>(x1);
+        b = pack8<CODE>(x2);
         // write_back == 0: the transformed K rows are only needed in the cache (the attention
         // kernel of this step reads them from there), so the pass over qkv is read-only
         if (write_back || !is_k) {
-            *reinterpret_cast<u32x2_t*>(p + 4 * j) = a;
-            *reinterpret_cast<u32x2_t*>(p + D / 2 + 4 * j) = b;
+            *reinterpret_cast<u32x4_t*>(p + 8 * j) = a;
+            *reinterpret_cast<u32x4_t*>(p + D / 2 + 8 * j) = b;
         }
     }
     if (active && (is_k || is_v) && k_cache != nullptr && slot_mapping != nullptr) {
@@ -262,14 +264,19 @@ __global__ void qk_norm_rope_store_kernel(
             const long at = blk * c_stride_b + off * c_stride_t + kvh * c_stride_h;
             if constexpr (KV8) {                 // one byte per element; from the 16-bit values
                 uint8_t* dst = reinterpret_cast<uint8_t*>(is_k ? k_cache : v_cache) + at;
-                unpack2<CODE>(a[0], x1[0], x1[1]); unpack2<CODE>(a[1], x1[2], x1[3]);
-                unpack2<CODE>(b[0], x2[0], x2[1]); unpack2<CODE>(b[1], x2[2], x2[3]);
-                *reinterpret_cast<uint32_t*>(dst + 4 * j) = pack_fp8x4(x1[0], x1[1], x1[2], x1[3]);
-                *reinterpret_cast<uint32_t*>(dst + D / 2 + 4 * j) = pack_fp8x4(x2[0], x2[1], x2[2], x2[3]);
+                unpack8<CODE>(a, x1);
+                unpack8<CODE>(b, x2);
+                u32x2_t lo, hi;
+                lo[0] = pack_fp8x4(x1[0], x1[1], x1[2], x1[3]);
+                lo[1] = pack_fp8x4(x1[4], x1[5], x1[6], x1[7]);
+                hi[0] = pack_fp8x4(x2[0], x2[1], x2[2], x2[3]);
+                hi[1] = pack_fp8x4(x2[4], x2[5], x2[6], x2[7]);
+                *reinterpret_cast<u32x2_t*>(dst + 8 * j) = lo;
+                *reinterpret_cast<u32x2_t*>(dst + D / 2 + 8 * j) = hi;
             } else {
                 uint16_t* dst = (is_k ? k_cache : v_cache) + at;
-                *reinterpret_cast<u32x2_t*>(dst + 4 * j) = a;
-                *reinterpret_cast<u32x2_t*>(dst + D / 2 + 4 * j) = b;
+                *reinterpret_cast<u32x4_t*>(dst + 8 * j) = a;
+                *reinterpret_cast<u32x4_t*>(dst + D / 2 + 8 * j) = b;
             }
         }
     }
@@ -286,7 +293,7 @@ extern "C" int mvl_qk_norm_rope_store(void* qkv, long qkv_stride, const int* pos
     if (T == 0) return 0;
     const int first_head = skip_q ? Hq : 0;
     const long rows = T * (Hq + 2 * Hkv - first_head);
-    const int rpw = 64 / (D / 8);
+    const int rpw = 64 / (D / 16);
     const int threads = 256;
     const long waves = (rows + rpw - 1) / rpw;
     const long blocks = (waves + 3) / 4;
