@@ -65,34 +65,6 @@ __device__ __forceinline__ int dec_tile_off(int row, int ch) {
     return row * (CPR * 16) + ((ch ^ x) << 4);
 }
 
-// 16 fp8 (e4m3) values -> 16 values of the 16-bit type CODE, as two 16-byte chunks.  The
-// scaled conversion with scale 1 is exact (every e4m3 value is a bf16 and an fp16 value) and
-// one instruction per pair, half of fp8 -> fp32 -> 16 bits.
-template <int CODE>
-__device__ __forceinline__ uint32_t widen_fp8x2(uint32_t v, bool high_word) {
-    if constexpr (CODE == 0) {
-        return high_word
-            ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, true))
-            : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, false));
-    } else {
-        return high_word
-            ? __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v, 1.0f, true))
-            : __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(v, 1.0f, false));
-    }
-}
-
-template <int CODE>
-__device__ __forceinline__ void widen_fp8x16(u32x4_t v, u32x4_t& lo, u32x4_t& hi) {
-    uint32_t o[8];
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-        o[2 * w] = widen_fp8x2<CODE>(v[w], false);
-        o[2 * w + 1] = widen_fp8x2<CODE>(v[w], true);
-    }
-    lo = u32x4_t{o[0], o[1], o[2], o[3]};
-    hi = u32x4_t{o[4], o[5], o[6], o[7]};
-}
-
 template <int CODE, int D, bool KV8>
 __global__ __launch_bounds__(256) void paged_decode_kernel(
         const uint16_t* __restrict__ q, long q_stride_b, long q_stride_h,

@@ -67,14 +67,21 @@ struct PrefillArgs {
 #define MVL_PROBE(slot, value) do { } while (0)
 #endif
 
-template <int CODE, int D, bool PAGED>
+// KV8 (paged only): the cache holds OCP fp8 (e4m3) bytes.  LDS-DMA cannot widen, so this variant
+// stages K/V tiles through registers: 16-byte loads of 16 fp8 values one tile ahead, widened to
+// the query's 16-bit type (exact) and written into the same swizzled LDS image after the current
+// tile's MFMA work; everything downstream of the LDS image is unchanged.
+template <int CODE, int D, bool PAGED, bool KV8 = false>
 __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs a) {
+    static_assert(!KV8 || PAGED, "an fp8 K/V source is always the paged cache");
     using DT = DType<CODE>;
     using vec8 = typename DT::vec8;
     constexpr int CPR = D / 8;
     constexpr int KSTEPS = D / 16;             // 32x32x16 k-steps over the head dim
     constexpr int NDB = D / 32;                // 32-wide blocks of the output head dim
     constexpr int ITER = kBN * CPR / kThreads; // staging chunks per thread per tile
+    constexpr int CPR8 = D / 16;               // 16-byte chunks of an fp8 row
+    constexpr int ITER8 = kBN * CPR8 / kThreads;
     constexpr int TILE_BYTES = kBN * D * 2;
 
     // two buffers of {K tile, V tile}; tile t lives in buffer t & 1
@@ -189,6 +196,44 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
         }
     };
 
+    // fp8 cache: thread owns chunks c = i * 256 + tid of the 64 x CPR8 tile, i.e. row c / CPR8,
+    // 16 fp8 values = LDS chunks 2 (c % CPR8) and 2 (c % CPR8) + 1 of that row
+    auto load_block_ids8 = [&](int t, int (&ids)[ITER8 > 0 ? ITER8 : 1]) {
+#pragma unroll
+        for (int i = 0; i < ITER8; ++i) {
+            const int tok = min(t * kBN + (i * kThreads + tid) / CPR8, k_len - 1);
+            ids[i] = bt[tok >> a.bs_log2];
+        }
+    };
+    auto load_tile8 = [&](int t, const int (&ids)[ITER8 > 0 ? ITER8 : 1],
+                          u32x4_t (&kr)[ITER8 > 0 ? ITER8 : 1], u32x4_t (&vr)[ITER8 > 0 ? ITER8 : 1]) {
+#pragma unroll
+        for (int i = 0; i < ITER8; ++i) {
+            const int c = i * kThreads + tid;
+            const int tok = min(t * kBN + c / CPR8, k_len - 1);
+            const long off = (long)ids[i] * a.cs_b + (long)(tok & bs_mask) * a.k_stride_t + head_off
+                             + (c % CPR8) * 16;                      // bytes = elements
+            kr[i] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint8_t*>(a.k) + off);
+            vr[i] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const uint8_t*>(a.v) + off);
+        }
+    };
+    auto write_tile8 = [&](int t, const u32x4_t (&kr)[ITER8 > 0 ? ITER8 : 1],
+                           const u32x4_t (&vr)[ITER8 > 0 ? ITER8 : 1]) {
+        char* kb = smem + (t & 1) * (2 * TILE_BYTES);
+#pragma unroll
+        for (int i = 0; i < ITER8; ++i) {
+            const int c = i * kThreads + tid;
+            const int row = c / CPR8, ch = 2 * (c % CPR8);
+            u32x4_t lo, hi;
+            widen_fp8x16<CODE>(kr[i], lo, hi);
+            *reinterpret_cast<u32x4_t*>(kb + tile_off<CPR>(row, ch)) = lo;
+            *reinterpret_cast<u32x4_t*>(kb + tile_off<CPR>(row, ch + 1)) = hi;
+            widen_fp8x16<CODE>(vr[i], lo, hi);
+            *reinterpret_cast<u32x4_t*>(kb + TILE_BYTES + tile_off<CPR>(row, ch)) = lo;
+            *reinterpret_cast<u32x4_t*>(kb + TILE_BYTES + tile_off<CPR>(row, ch + 1)) = hi;
+        }
+    };
+
     float m_run = -INFINITY, l_run = 0.f;
     f32x16_t acc_o[NDB];
 #pragma unroll
@@ -211,7 +256,14 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     }
 
     int ids_next[ITER];
-    {
+    int ids8_next[ITER8 > 0 ? ITER8 : 1];
+    u32x4_t kraw[ITER8 > 0 ? ITER8 : 1], vraw[ITER8 > 0 ? ITER8 : 1];
+    if constexpr (KV8) {
+        int ids[ITER8 > 0 ? ITER8 : 1];
+        load_block_ids8(0, ids);
+        load_tile8(0, ids, kraw, vraw);
+        if (n_tiles > 1) load_block_ids8(1, ids8_next);
+    } else {
         int ids[ITER];
         load_block_ids(0, ids);
         stage_tile(0, ids);
@@ -255,6 +307,7 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) qfrag[s] = __builtin_bit_cast(vec8, pack8<CODE>(f[s]));
     }
+    if constexpr (KV8) write_tile8(0, kraw, vraw);
     __syncthreads();                         // drains the LDS-DMA (vmcnt) and meets the waves
     MVL_PROBE(1, wall_clock64());
     MVL_PROBE(4, (unsigned long long)n_tiles);
@@ -350,16 +403,24 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
         for (int t = t_begin; t < t_end; ++t) {
             if (t + 1 < n_tiles) {
                 // buffer (t+1)&1 was last read in iteration t-1; the barrier that closed it
-                // ordered those reads before this DMA
-                stage_tile(t + 1, ids_next);
-                if (t + 2 < n_tiles) load_block_ids(t + 2, ids_next);
+                // ordered those reads before this DMA (KV8: before the writes further down)
+                if constexpr (KV8) {
+                    load_tile8(t + 1, ids8_next, kraw, vraw);
+                    if (t + 2 < n_tiles) load_block_ids8(t + 2, ids8_next);
+                } else {
+                    stage_tile(t + 1, ids_next);
+                    if (t + 2 < n_tiles) load_block_ids(t + 2, ids_next);
+                }
             }
             const int kv0 = t * kBN;
             if (wave_live && kv0 <= wave_max_pos) {
                 const char* k_lds = smem + (t & 1) * (2 * TILE_BYTES);
                 process_tile(mask_tag, kv0, k_lds, k_lds + TILE_BYTES);
             }
-            if (t + 1 < n_tiles) __syncthreads();    // tile t+1 has landed, tile t is free
+            if (t + 1 < n_tiles) {
+                if constexpr (KV8) write_tile8(t + 1, kraw, vraw);
+                __syncthreads();                     // tile t+1 has landed, tile t is free
+            }
         }
     };
     const int t_split = min(n_tiles, (q0 + pos_off + 1) / kBN);   // uniform for the workgroup
@@ -387,10 +448,10 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     }   // pass
 }
 
-template <int CODE, int D, bool PAGED>
+template <int CODE, int D, bool PAGED, bool KV8 = false>
 int launch_prefill(PrefillArgs a, hipStream_t st) {
     const size_t lds = 2 * 2 * (size_t)kBN * D * 2;      // double-buffered K and V tiles
-    flash_prefill_kernel<CODE, D, PAGED><<<a.total_wg, kThreads, lds, st>>>(a);
+    flash_prefill_kernel<CODE, D, PAGED, KV8><<<a.total_wg, kThreads, lds, st>>>(a);
     return MVL_CHECK_LAUNCH();
 }
 
@@ -399,16 +460,19 @@ int launch_prefill(PrefillArgs a, hipStream_t st) {
 // positions / cos_sin / q_w / eps: see PrefillArgs (cos_sin null: q is already transformed).
 // paged == 0: k/v are packed [T, Hkv, D] tensors (token stride k_stride_t, head stride
 // k_stride_h), cu_k may equal cu_q.  paged == 1: k/v are caches addressed by
-// (block stride cs_b, token stride k_stride_t, head stride k_stride_h) through block_tables.
+// (block stride cs_b, token stride k_stride_t, head stride k_stride_h) through block_tables;
+// kv_fp8 != 0: the caches hold OCP fp8 (e4m3) bytes (strides in bytes).
 extern "C" int mvl_flash_attention_prefill(
         const void* q, long q_stride_t, long q_stride_h, const void* k, const void* v,
         long k_stride_t, long k_stride_h, long cs_b, void* out, long o_stride_t, long o_stride_h,
         const int* cu_q, const int* cu_k, const int* block_tables, int bt_stride, int block_size,
         float scale, int B, int Hq, int Hkv, int D, int max_q_len, int paged, int dtype,
-        const int* positions, const float* cos_sin, const void* q_w, float eps, void* stream) {
+        const int* positions, const float* cos_sin, const void* q_w, float eps, int kv_fp8,
+        void* stream) {
     if (B == 0 || max_q_len <= 0) return 0;
     if ((D != 64 && D != 128) || Hq % Hkv != 0) return -1;
     if (paged && (block_size & (block_size - 1))) return -1;
+    if (kv_fp8 && !paged) return -1;
     PrefillArgs a;
     a.q = (const uint16_t*)q; a.q_stride_t = q_stride_t; a.q_stride_h = q_stride_h;
     a.k = (const uint16_t*)k; a.v = (const uint16_t*)v;
@@ -433,7 +497,8 @@ extern "C" int mvl_flash_attention_prefill(
     a.positions = positions; a.cos_sin = cos_sin; a.q_w = (const uint16_t*)q_w; a.eps = eps;
     auto st = (hipStream_t)stream;
 #define MVL_PRE(CODE, DD)                                                         \
-    return paged ? launch_prefill<CODE, DD, true>(a, st) : launch_prefill<CODE, DD, false>(a, st)
+    return kv_fp8 ? launch_prefill<CODE, DD, true, true>(a, st)                   \
+         : paged  ? launch_prefill<CODE, DD, true>(a, st) : launch_prefill<CODE, DD, false>(a, st)
     if (dtype == 0) { if (D == 128) MVL_PRE(0, 128); else MVL_PRE(0, 64); }
     else            { if (D == 128) MVL_PRE(1, 128); else MVL_PRE(1, 64); }
 #undef MVL_PRE

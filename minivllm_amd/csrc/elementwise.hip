@@ -314,75 +314,6 @@ extern "C" int mvl_qk_norm_rope_store(void* qkv, long qkv_stride, const int* pos
     return MVL_CHECK_LAUNCH();
 }
 
-// ============================================ fp8 KV cache -> packed 16-bit K/V
-// For prefill steps that attend to cached tokens of an fp8 cache: the keys/values of every
-// sequence of the step (its whole context, through the block table) are widened into packed
-// [sum k_len, Hkv, D] tensors of the query's dtype, which the flash-prefill kernel then reads
-// like freshly projected K/V.  (Prefill is bound by its GEMMs; the decode kernel, which is
-// bound by KV bytes, reads the fp8 cache directly.)  grid = (chunks of the longest context, B),
-// one 16-byte cache chunk (16 elements) per thread.
-template <int CODE>
-__global__ void kv_gather_widen_kernel(const uint8_t* __restrict__ k_cache,
-                                       const uint8_t* __restrict__ v_cache, long cs_b, long cs_t,
-                                       long cs_h, int bs_log2, const int* __restrict__ block_tables,
-                                       int bt_stride, const int* __restrict__ cu_k,
-                                       uint16_t* __restrict__ k_out, uint16_t* __restrict__ v_out,
-                                       int Hkv, int D) {
-    const int b = blockIdx.y;
-    const int k_start = cu_k[b], k_len = cu_k[b + 1] - k_start;
-    const int cpr = D / 16, cpt = Hkv * cpr;              // chunks per row / per token
-    const long total = (long)k_len * cpt;
-    const int* bt = block_tables + (long)b * bt_stride;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
-        const int tok = (int)(idx / cpt);
-        const int r = (int)(idx - (long)tok * cpt);
-        const int h = r / cpr, c = r - h * cpr;
-        const long src = (long)bt[tok >> bs_log2] * cs_b + (long)(tok & ((1 << bs_log2) - 1)) * cs_t +
-                         (long)h * cs_h + c * 16;
-        const long dst = ((long)(k_start + tok) * Hkv + h) * D + c * 16;
-#pragma unroll
-        for (int which = 0; which < 2; ++which) {
-            const u32x4_t v = *reinterpret_cast<const u32x4_t*>((which ? v_cache : k_cache) + src);
-            uint32_t o[8];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const auto f01 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], false);
-                const auto f23 = __builtin_amdgcn_cvt_pk_f32_fp8((int)v[w], true);
-                o[2 * w] = pack2<CODE>(f01[0], f01[1]);
-                o[2 * w + 1] = pack2<CODE>(f23[0], f23[1]);
-            }
-            u32x4_t* out = reinterpret_cast<u32x4_t*>((which ? v_out : k_out) + dst);
-            out[0] = u32x4_t{o[0], o[1], o[2], o[3]};
-            out[1] = u32x4_t{o[4], o[5], o[6], o[7]};
-        }
-    }
-}
-
-// k_out / v_out: [cu_k[B], Hkv, D] contiguous.  max_k_len bounds the grid only.
-extern "C" int mvl_kv_gather_widen(const void* k_cache, const void* v_cache, long cs_b, long cs_t,
-                                   long cs_h, int block_size, const int* block_tables,
-                                   int bt_stride, const int* cu_k, void* k_out, void* v_out, int B,
-                                   int Hkv, int D, int max_k_len, int dtype, void* stream) {
-    if (D % 16 != 0 || (block_size & (block_size - 1))) return -1;
-    if (B == 0 || max_k_len == 0) return 0;
-    int bs_log2 = 0;
-    while ((1 << bs_log2) < block_size) ++bs_log2;
-    long per_seq = ((long)max_k_len * Hkv * (D / 16) + 255) / 256;
-    if (per_seq > 4096) per_seq = 4096;
-    dim3 grid((unsigned)per_seq, (unsigned)B);
-    auto st = (hipStream_t)stream;
-    if (dtype == 0)
-        kv_gather_widen_kernel<0><<<grid, 256, 0, st>>>(
-            (const uint8_t*)k_cache, (const uint8_t*)v_cache, cs_b, cs_t, cs_h, bs_log2, block_tables,
-            bt_stride, cu_k, (uint16_t*)k_out, (uint16_t*)v_out, Hkv, D);
-    else
-        kv_gather_widen_kernel<1><<<grid, 256, 0, st>>>(
-            (const uint8_t*)k_cache, (const uint8_t*)v_cache, cs_b, cs_t, cs_h, bs_log2, block_tables,
-            bt_stride, cu_k, (uint16_t*)k_out, (uint16_t*)v_out, Hkv, D);
-    return MVL_CHECK_LAUNCH();
-}
-
 // ======================================================== standalone KV store
 // key/value: [T, Hkv, D] with a token stride; one 16-byte chunk per thread.
 __global__ void store_kvcache_kernel(const uint16_t* __restrict__ key,

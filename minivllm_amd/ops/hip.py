@@ -43,9 +43,6 @@ _silu = _sig("mvl_silu_and_mul", _c_void, _c_void, _c_long, _c_int, _c_long, _c_
 _rope = _sig("mvl_qk_norm_rope_store", _c_void, _c_long, _c_void, _c_void, _c_void, _c_void,
              _c_float, _c_long, _c_int, _c_int, _c_int, _c_void, _c_void, _c_long, _c_long,
              _c_long, _c_int, _c_void, _c_int, _c_int, _c_int, _c_int, _c_void)
-_gather_widen = _sig("mvl_kv_gather_widen", _c_void, _c_void, _c_long, _c_long, _c_long, _c_int,
-                     _c_void, _c_int, _c_void, _c_void, _c_void, _c_int, _c_int, _c_int, _c_int,
-                     _c_int, _c_void)
 _store = _sig("mvl_store_kvcache", _c_void, _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
               _c_long, _c_long, _c_int, _c_void, _c_long, _c_int, _c_int, _c_void)
 _sample = _sig("mvl_sample", _c_void, _c_long, _c_int, _c_int, _c_int, _c_int, _c_void, _c_u64,
@@ -60,7 +57,7 @@ _decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void,
 _prefill = _sig("mvl_flash_attention_prefill", _c_void, _c_long, _c_long, _c_void, _c_void,
                 _c_long, _c_long, _c_long, _c_void, _c_long, _c_long, _c_void, _c_void, _c_void,
                 _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                _c_void, _c_void, _c_void, _c_float, _c_void)
+                _c_void, _c_void, _c_void, _c_float, _c_int, _c_void)
 
 _naive = _sig("mvl_naive_attention", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long, _c_long,
               _c_void, _c_long, _c_long, _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -271,7 +268,7 @@ def flash_attention_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     _check(_prefill(q.data_ptr(), qs_t, qs_h, k.data_ptr(), v.data_ptr(), ks_t, ks_h, 0,
                     out.data_ptr(), out.stride(0), out.stride(1), cu.data_ptr(), cu.data_ptr(),
                     None, 0, 1, scale, cu.numel() - 1, hq, hkv, d, max_seqlen, 0, _dt(q),
-                    pos.data_ptr() if pos is not None else None, cs, qw, eps,
+                    pos.data_ptr() if pos is not None else None, cs, qw, eps, 0,
                     _stream()), "flash_attention_prefill")
     return out
 
@@ -304,18 +301,21 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
                             out: Optional[torch.Tensor] = None,
                             max_seqlen_k: Optional[int] = None,
                             total_k: Optional[int] = None, q_rope=None) -> torch.Tensor:
+    """Causal prefill through the block table (``q_len <= k_len`` per sequence).  An fp8 (e4m3)
+    cache is read by the same kernel, which widens the tiles while staging them;
+    ``max_seqlen_k`` / ``total_k`` are accepted for callers that know them and not needed."""
     T, hq, d = q.shape
     hkv = k_cache.shape[2]
     cq, ck, bt = _i32(cu_seqlens_q), _i32(cu_seqlens_k), _i32(block_tables)
     if max_seqlen_q is None:
         max_seqlen_q = int((cq[1:] - cq[:-1]).max().item())
-    if _kv_fp8(k_cache):
-        return _prefill_over_fp8_cache(q, k_cache, v_cache, cq, ck, bt, scale, max_seqlen_q,
-                                       max_seqlen_k, total_k, out, q_rope)
     qs_t, qs_h = _q_strides(q)
     sb, st, sh = _cache_strides(k_cache)
     assert _cache_strides(v_cache) == (sb, st, sh)
     assert bt.stride(1) == 1
+    if _kv_fp8(k_cache):        # 16-byte chunks of 16 values
+        assert d % 16 == 0 and st % 16 == 0 and sh % 16 == 0 and sb % 16 == 0 \
+            and k_cache.data_ptr() % 16 == 0 and v_cache.data_ptr() % 16 == 0
     if out is None:
         out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
     assert out.shape == (T, hq, d) and out.stride(2) == 1 and out.dtype == q.dtype
@@ -324,37 +324,7 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
                     out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
                     bt.data_ptr(), bt.stride(0), k_cache.shape[1], scale, cq.numel() - 1, hq, hkv,
                     d, max_seqlen_q, 1, _dt(q), pos.data_ptr() if pos is not None else None, cs, qw,
-                    eps, _stream()), "paged_attention_prefill")
-    return out
-
-
-def _prefill_over_fp8_cache(q, k_cache, v_cache, cq, ck, bt, scale, max_seqlen_q, max_seqlen_k,
-                            total_k, out, q_rope=None):
-    """fp8 cache: widen the contexts of the step's sequences into packed 16-bit K/V
-    (``kv_gather_widen``), then run the packed flash kernel with separate q / k lengths."""
-    T, hq, d = q.shape
-    hkv = k_cache.shape[2]
-    B = cq.numel() - 1
-    if max_seqlen_k is None:                                        # stand-alone call: ask the device
-        max_seqlen_k = int((ck[1:] - ck[:-1]).max().item())
-        total_k = int(ck[-1].item())
-    rows = total_k if total_k else B * max_seqlen_k                 # upper bound without a sync
-    k = torch.empty((rows, hkv, d), dtype=q.dtype, device=q.device)
-    v = torch.empty_like(k)
-    sb, st, sh = _cache_strides(k_cache)
-    assert _cache_strides(v_cache) == (sb, st, sh) and bt.stride(1) == 1
-    _check(_gather_widen(k_cache.data_ptr(), v_cache.data_ptr(), sb, st, sh, k_cache.shape[1],
-                         bt.data_ptr(), bt.stride(0), ck.data_ptr(), k.data_ptr(), v.data_ptr(), B,
-                         hkv, d, max_seqlen_k, _dt(q), _stream()), "kv_gather_widen")
-    qs_t, qs_h = _q_strides(q)
-    if out is None:
-        out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
-    pos, cs, qw, eps = _q_rope_args(q, q_rope)
-    _check(_prefill(q.data_ptr(), qs_t, qs_h, k.data_ptr(), v.data_ptr(), k.stride(0), k.stride(1),
-                    0, out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
-                    None, 0, 1, scale, B, hq, hkv, d, max_seqlen_q, 0, _dt(q),
-                    pos.data_ptr() if pos is not None else None, cs, qw, eps, _stream()),
-           "flash_attention_prefill (fp8 cache)")
+                    eps, _kv_fp8(k_cache), _stream()), "paged_attention_prefill")
     return out
 
 
