@@ -42,6 +42,24 @@ def test_sequence_pickle_is_compact_and_complete():
     assert len(pickle.dumps(s)) < len(pickle.dumps(list(range(2000))))
 
 
+def test_sequence_token_array_follows_the_token_list():
+    """The int32 image used for batch preparation: prompt slices are views of one cached array,
+    a range that reaches into generated tokens (re-prefill after preemption) rebuilds it, and an
+    unpickled sequence (no image) builds it on demand."""
+    import pickle
+    import numpy as np
+    s = Sequence(list(range(100, 110)), SamplingParams(max_tokens=8), block_size=4)
+    a = s.token_array(0, 10)
+    assert a.dtype == np.int32 and a.tolist() == list(range(100, 110))
+    assert np.shares_memory(a, s.token_array(2, 5)) and s.token_array(2, 5).tolist() == [102, 103, 104]
+    s.append_token(7)
+    s.append_token(8)
+    assert s.token_array(0, 12).tolist() == list(range(100, 110)) + [7, 8]       # rebuilt
+    assert s.token_array(10, 12).tolist() == [7, 8]
+    r = pickle.loads(pickle.dumps(Sequence([5, 6, 7], block_size=4)))
+    assert r.token_array(1, 3).tolist() == [6, 7]
+
+
 def test_sampling_params_validation():
     assert SamplingParams(temperature=0).greedy
     with pytest.raises(ValueError):
