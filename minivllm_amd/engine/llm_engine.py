@@ -196,6 +196,7 @@ class LLMEngine:
                 finally:
                     self._in_step = 0
                 finished = self.scheduler.postprocess(seqs, token_ids)
+                self._drop_stale_prelaunch()
                 return ([(s.seq_id, s.completion_token_ids) for s in finished], len(seqs), False)
         seqs, is_prefill = self.scheduler.schedule()
         if not seqs:
@@ -219,7 +220,16 @@ class LLMEngine:
         finally:
             self._in_step = 0
         finished = self.scheduler.postprocess(seqs, token_ids)
+        self._drop_stale_prelaunch()
         return ([(s.seq_id, s.completion_token_ids) for s in finished], num_tokens, is_prefill)
+
+    def _drop_stale_prelaunch(self) -> None:
+        """A decode step launched ahead whose sequences have all just finished would otherwise
+        outlive the loop that drives ``step()`` (``generate`` stops as soon as the scheduler is
+        empty) and be found by the next, unrelated use of the runner."""
+        runner = self.model_runner
+        if runner.has_prelaunched() and self.scheduler.is_finished():
+            runner.drop_prelaunched()
 
     def is_finished(self) -> bool:
         return self.scheduler.is_finished()

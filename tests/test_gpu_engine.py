@@ -464,3 +464,31 @@ def test_decode_steps_launched_ahead_do_not_change_outputs(gpu):
     plain_s, _ = run(False, stop)
     ahead_s, _ = run(True, stop)
     assert ahead_s == plain_s and len(plain_s[1]) <= 21 and len(plain_s[7]) <= 12
+
+
+@pytest.mark.gpu
+def test_driver_smoke_entry_runs(gpu):
+    """``__graft_entry__.smoke()``: generate through the engine (decode steps launched ahead), then
+    drive the same runner directly for the logit check.  A launched-ahead step that outlives
+    ``generate`` (all its sequences finished in the step that launched it) must have been
+    dropped by then."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    entry = importlib.import_module("__graft_entry__")
+    entry.smoke()
+
+
+@pytest.mark.gpu
+def test_no_launched_ahead_step_survives_generate(gpu):
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    cfg = dict(model_preset="qwen3-0.6b", num_layers=2, max_num_sequences=8, max_num_batched_tokens=1024,
+               block_size=256, max_model_length=512, eos=-1, max_cached_blocks=32, dtype="bf16",
+               device="cuda", graph_batch_sizes=[4, 8])
+    eng = LLMEngine(cfg)
+    prompts = [torch.randint(0, 1000, (n,)).tolist() for n in (40, 17, 90)]
+    eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
+    assert eng.is_finished() and not eng.model_runner.has_prelaunched()
+    eng.exit()
