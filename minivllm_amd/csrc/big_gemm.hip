@@ -6,14 +6,16 @@
 // Shape of the kernel (gfx950, wave64):
 //  * one workgroup of 8 waves owns a 256 x 256 output tile and walks K in 64-element tiles;
 //    LDS holds two K-tiles, each as four half-tiles of 128 rows x 128 bytes:
-//    A0 / A1 = x rows 0..127 / 128..255, B0 / B1 = W rows 0..127 / 128..255 of the tile
-//    (SwiGLU: B0 = 128 gate columns, B1 = the matching 128 up columns);
+//    A0 / A1 = x rows 0..127 / 128..255 of the tile; B0 / B1 = for each of the four wave columns
+//    the first / last 32 of its 64 consecutive output columns (so that a wave stores whole
+//    128-byte rows); SwiGLU: B0 = 128 gate columns, B1 = the matching 128 up columns;
 //  * wave (wr, wc), wr = 0..1, wc = 0..3, owns x rows {64 wr .. +63} of A0 ("top") and of A1
 //    ("bottom") and W rows {32 wc .. +31} of B0 ("left") and of B1 ("right"): four 64 x 32
 //    quadrants, 128 accumulator registers.  A K-tile is four phases, one quadrant each, in the
 //    order (top,left) (top,right) (bottom,right) (bottom,left), so the fragment reads are
 //    12 / 4 / 8 / 0 ds_read_b128 and the half-tiles are first needed in the order A0 B0 B1 A1;
-//  * every phase requests one half-tile (2 LDS-DMA instructions per wave) and waits with a
+//  * every phase requests one half-tile (2 LDS-DMA instructions per wave, buffer form: 32-bit
+//    per-lane offsets, range-checked) and waits with a
 //    counted vmcnt for the half-tile requested four phases earlier; a half-tile is read no
 //    earlier than the phase after that wait and overwritten no earlier than two phases after
 //    its last read.  Nothing in the loop drains the vector-memory queue;
