@@ -364,7 +364,12 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
             m_run = m_new;
         }
         const float m_use = (m_run == -INFINITY) ? 0.f : m_run;
-        float psum = 0.f;
+        // the softmax arithmetic shares the SIMD's issue slots with the MFMAs (the kernel's time
+        // is the sum of the two), so it runs two values per instruction where the ISA allows:
+        // packed FMA for the exponent arguments, packed adds for the row sums
+        typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+        const f32x2_t scale2 = {a.scale_log2, a.scale_log2}, negm2 = {-m_use, -m_use};
+        f32x2_t psum2 = {0.f, 0.f};
         vec8 pfrag[2][2];
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub)
@@ -372,13 +377,17 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
             for (int s = 0; s < 2; ++s) {
                 float p[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    p[j] = __builtin_amdgcn_exp2f(fmaf(s_acc[sub][8 * s + j], a.scale_log2, -m_use));
-                    psum += p[j];
+                for (int j = 0; j < 8; j += 2) {
+                    const f32x2_t sv = {s_acc[sub][8 * s + j], s_acc[sub][8 * s + j + 1]};
+                    const f32x2_t arg = __builtin_elementwise_fma(sv, scale2, negm2);
+                    const f32x2_t pv = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+                    psum2 += pv;
+                    p[j] = pv[0];
+                    p[j + 1] = pv[1];
                 }
                 pfrag[sub][s] = __builtin_bit_cast(vec8, pack8<CODE>(p));
             }
-        l_run += psum;
+        l_run += psum2[0] + psum2[1];
 #pragma unroll
         for (int n = 0; n < NDB; ++n) {
 #pragma unroll
