@@ -71,9 +71,16 @@ struct PrefillArgs {
 // stages K/V tiles through registers: 16-byte loads of 16 fp8 values one tile ahead, widened to
 // the query's 16-bit type (exact) and written into the same swizzled LDS image after the current
 // tile's MFMA work; everything downstream of the LDS image is unchanged.
-template <int CODE, int D, bool PAGED, bool KV8 = false>
+// UNI: every row of a 64-row K/V tile comes from one uniform base (packed K/V, or a paged cache
+// whose blocks hold a multiple of 64 tokens).  The tile is then described by a buffer descriptor
+// built from scalars (block id, token offset, valid rows) and each lane's source offset is a
+// constant of the kernel: no per-lane 64-bit address arithmetic and no per-lane block-table
+// loads in the loop (those were ~70 of the ~240 vector-ALU instructions of a tile, and this
+// kernel's time is the sum of its MFMA and vector-ALU issue).  Rows beyond the context read as 0.
+template <int CODE, int D, bool PAGED, bool KV8 = false, bool UNI = false>
 __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs a) {
     static_assert(!KV8 || PAGED, "an fp8 K/V source is always the paged cache");
+    static_assert(!(KV8 && UNI), "the fp8 arm stages through registers");
     using DT = DType<CODE>;
     using vec8 = typename DT::vec8;
     constexpr int CPR = D / 8;
@@ -196,6 +203,35 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
         }
     };
 
+    // UNI: constant per-lane byte offsets inside a tile, the rest of the address is uniform
+    uint32_t voff[ITER];
+#pragma unroll
+    for (int i = 0; i < ITER; ++i)
+        voff[i] = (uint32_t)st_row[i] * (uint32_t)(a.k_stride_t * 2) + (uint32_t)st_ch[i] * 16u;
+    auto tile_block = [&](int t) -> int {
+        return PAGED ? __builtin_amdgcn_readfirstlane(bt[(t * kBN) >> a.bs_log2]) : 0;
+    };
+    auto stage_tile_uni = [&](int t, int blk) {
+        char* kb = smem + (t & 1) * (2 * TILE_BYTES);
+        const int tok0 = t * kBN;
+        const long off = PAGED ? (long)blk * a.cs_b + (long)(tok0 & bs_mask) * a.k_stride_t + head_off
+                               : (long)(k_start + tok0) * a.k_stride_t + head_off;
+        const int bytes = min(kBN, k_len - tok0) * (int)(a.k_stride_t * 2);
+        const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(a.k + off), 0, bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rv = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t*>(a.v + off), 0, bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < ITER; ++i) {
+            char* dst = kb + (i * kThreads + w * 64) * 16;          // wave-uniform
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rk, (__attribute__((address_space(3))) void*)dst, 16, (int)voff[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rv, (__attribute__((address_space(3))) void*)(dst + TILE_BYTES), 16, (int)voff[i], 0, 0, 0);
+        }
+    };
+    int blk_next = 0;
+
     // fp8 cache: thread owns chunks c = i * 256 + tid of the 64 x CPR8 tile, i.e. row c / CPR8,
     // 16 fp8 values = LDS chunks 2 (c % CPR8) and 2 (c % CPR8) + 1 of that row
     auto load_block_ids8 = [&](int t, int (&ids)[ITER8 > 0 ? ITER8 : 1]) {
@@ -263,6 +299,9 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
         load_block_ids8(0, ids);
         load_tile8(0, ids, kraw, vraw);
         if (n_tiles > 1) load_block_ids8(1, ids8_next);
+    } else if constexpr (UNI) {
+        stage_tile_uni(0, tile_block(0));
+        if (n_tiles > 1) blk_next = tile_block(1);
     } else {
         int ids[ITER];
         load_block_ids(0, ids);
@@ -416,6 +455,9 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
                 if constexpr (KV8) {
                     load_tile8(t + 1, ids8_next, kraw, vraw);
                     if (t + 2 < n_tiles) load_block_ids8(t + 2, ids8_next);
+                } else if constexpr (UNI) {
+                    stage_tile_uni(t + 1, blk_next);
+                    if (t + 2 < n_tiles) blk_next = tile_block(t + 2);
                 } else {
                     stage_tile(t + 1, ids_next);
                     if (t + 2 < n_tiles) load_block_ids(t + 2, ids_next);
@@ -457,10 +499,10 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     }   // pass
 }
 
-template <int CODE, int D, bool PAGED, bool KV8 = false>
+template <int CODE, int D, bool PAGED, bool KV8 = false, bool UNI = false>
 int launch_prefill(PrefillArgs a, hipStream_t st) {
     const size_t lds = 2 * 2 * (size_t)kBN * D * 2;      // double-buffered K and V tiles
-    flash_prefill_kernel<CODE, D, PAGED, KV8><<<a.total_wg, kThreads, lds, st>>>(a);
+    flash_prefill_kernel<CODE, D, PAGED, KV8, UNI><<<a.total_wg, kThreads, lds, st>>>(a);
     return MVL_CHECK_LAUNCH();
 }
 
@@ -504,10 +546,16 @@ extern "C" int mvl_flash_attention_prefill(
     a.total_wg = B * Hq * a.n_items;
     if (cos_sin != nullptr && positions == nullptr) return -1;
     a.positions = positions; a.cos_sin = cos_sin; a.q_w = (const uint16_t*)q_w; a.eps = eps;
+    // one uniform base per K/V tile: blocks of a multiple of 64 tokens, tile strides within 31 bits
+    static const char* uni_env = getenv("MVL_PREFILL_UNI");
+    const bool uni = (uni_env ? atoi(uni_env) != 0 : true) && block_size % kBN == 0
+                     && k_stride_t * 2 * kBN < (1l << 31);
     auto st = (hipStream_t)stream;
 #define MVL_PRE(CODE, DD)                                                         \
     return kv_fp8 ? launch_prefill<CODE, DD, true, true>(a, st)                   \
-         : paged  ? launch_prefill<CODE, DD, true>(a, st) : launch_prefill<CODE, DD, false>(a, st)
+         : !paged ? launch_prefill<CODE, DD, false, false, true>(a, st)           \
+         : uni    ? launch_prefill<CODE, DD, true, false, true>(a, st)            \
+                  : launch_prefill<CODE, DD, true>(a, st)
     if (dtype == 0) { if (D == 128) MVL_PRE(0, 128); else MVL_PRE(0, 64); }
     else            { if (D == 128) MVL_PRE(1, 128); else MVL_PRE(1, 64); }
 #undef MVL_PRE
