@@ -208,8 +208,12 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 #pragma unroll
     for (int i = 0; i < ITER; ++i)
         voff[i] = (uint32_t)st_row[i] * (uint32_t)(a.k_stride_t * 2) + (uint32_t)st_ch[i] * 16u;
+    // the tile's block id through the scalar unit (the table is read-only for the kernel): a
+    // vector load would be waited for with vmcnt(0), i.e. together with the K/V requests in flight
     auto tile_block = [&](int t) -> int {
-        return PAGED ? __builtin_amdgcn_readfirstlane(bt[(t * kBN) >> a.bs_log2]) : 0;
+        if (!PAGED) return 0;
+        typedef const __attribute__((address_space(4))) int* const_int_p;
+        return *(const_int_p)(uintptr_t)(bt + ((t * kBN) >> a.bs_log2));
     };
     auto stage_tile_uni = [&](int t, int blk) {
         char* kb = smem + (t & 1) * (2 * TILE_BYTES);
@@ -427,20 +431,56 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
                 pfrag[sub][s] = __builtin_bit_cast(vec8, pack8<CODE>(p));
             }
         l_run += psum2[0] + psum2[1];
+        if constexpr (!UNI) {
 #pragma unroll
-        for (int n = 0; n < NDB; ++n) {
+            for (int n = 0; n < NDB; ++n) {
 #pragma unroll
-            for (int sub = 0; sub < 2; ++sub)
+                for (int sub = 0; sub < 2; ++sub)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    // k-slot j of lane half hh <-> key 32 sub + 16 s + 8 (j>>2) + 4 hh + (j&3)
-                    const int row = 32 * sub + 16 * s + tr_row0;
-                    const int ch = 4 * n + tr_chunk0;
-                    const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(row, ch) + tr_sub);
-                    const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(row + 8, ch) + tr_sub);
-                    const s16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                    acc_o[n] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[sub][s], acc_o[n]);
+                    for (int s = 0; s < 2; ++s) {
+                        // k-slot j of lane half hh <-> key 32 sub + 16 s + 8 (j>>2) + 4 hh + (j&3)
+                        const int row = 32 * sub + 16 * s + tr_row0;
+                        const int ch = 4 * n + tr_chunk0;
+                        const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(row, ch) + tr_sub);
+                        const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(row + 8, ch) + tr_sub);
+                        const s16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                        acc_o[n] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[sub][s], acc_o[n]);
+                    }
+            }
+        } else {
+            // Through the builtin the compiler waits for EVERY LDS-DMA request in flight
+            // (vmcnt(0)) before the first transposed read, i.e. for the next tile, requested at
+            // the top of this iteration and needed only after its closing barrier.  As inline asm
+            // the reads carry no such wait; their own lgkmcnt waits are written out: fragments
+            // of step i + 2 are requested before step i's MFMA, and LDS returns in order, so "at
+            // most 4 outstanding" means the pair of step i has arrived.
+            constexpr int NPV = 4 * NDB;
+            const uint32_t v_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)v_lds;
+            s16x4_t vlo[NPV], vhi[NPV];
+            auto v_read = [&](int i) {
+                const int n = i / 4, sub = (i >> 1) & 1, s = i & 1;
+                const int row = 32 * sub + 16 * s + tr_row0;
+                const int ch = 4 * n + tr_chunk0;
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[i])
+                             : "v"(v_base + tile_off<CPR>(row, ch) + tr_sub));
+                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vhi[i])
+                             : "v"(v_base + tile_off<CPR>(row + 8, ch) + tr_sub));
+            };
+            v_read(0);
+            v_read(1);
+#pragma unroll
+            for (int i = 0; i < NPV; ++i) {
+                if (i + 2 < NPV) {
+                    v_read(i + 2);
+                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vlo[i]), "+v"(vhi[i]));
+                } else if (i + 1 < NPV) {
+                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vlo[i]), "+v"(vhi[i]));
+                } else {
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[i]), "+v"(vhi[i]));
                 }
+                const s16x8_t av = __builtin_shufflevector(vlo[i], vhi[i], 0, 1, 2, 3, 4, 5, 6, 7);
+                acc_o[i / 4] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[(i >> 1) & 1][i & 1], acc_o[i / 4]);
+            }
         }
     };
 

@@ -41,28 +41,43 @@ int main(int argc, char** argv) {
     CK(hipMemcpy(dcu, cu.data(), (B + 1) * 4, hipMemcpyHostToDevice));
     PrefillArgs a;
     a.q = q; a.q_stride_t = (long)Hq * D; a.q_stride_h = D;
-    a.k = k; a.v = v; a.k_stride_t = (long)Hkv * D; a.k_stride_h = D; a.cs_b = 0;
+    // K/V head-major ([Hkv][T][D]): a 64-token tile is one contiguous 16 KiB piece, as in the
+    // paged cache with blocks of >= 64 tokens (token-major [T][Hkv][D] rows, 2 KiB apart, run
+    // the kernel about half as fast: MVL_PROBE_TOKEN_MAJOR=1)
+    const bool token_major = getenv("MVL_PROBE_TOKEN_MAJOR") != nullptr;
+    a.k = k; a.v = v; a.cs_b = 0;
+    a.k_stride_t = token_major ? (long)Hkv * D : D;
+    a.k_stride_h = token_major ? D : T * D;
     a.out = o; a.o_stride_t = (long)Hq * D; a.o_stride_h = D;
     a.cu_q = dcu; a.cu_k = dcu; a.block_tables = nullptr; a.bt_stride = 0; a.bs_log2 = 0;
     a.scale_log2 = kLog2e / sqrtf((float)D);
     a.B = B; a.Hq = Hq; a.Hkv = Hkv;
     a.positions = nullptr; a.cos_sin = nullptr; a.q_w = nullptr; a.eps = 0.f;
     a.n_qtiles = (S + kBM - 1) / kBM;
-    a.pair = 0; a.n_items = a.n_qtiles;          // one Q tile per workgroup: the stamps are per tile count
+    // default: one Q tile per workgroup (the stamps are per tile count); argv[5] = pairs per workgroup
+    a.pair = argc > 5 ? atoi(argv[5]) : 0;
+    a.n_items = a.pair ? ((a.n_qtiles + 1) / 2 + a.pair - 1) / a.pair : a.n_qtiles;
     a.total_wg = B * Hq * a.n_qtiles;
     CK(hipMalloc(&probe, (size_t)a.total_wg * 8 * 8));
     CK(hipMemset(probe, 0, (size_t)a.total_wg * 8 * 8));
     a.probe = probe;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float ms = 0.f;
+    const bool quiet = argc > 6;                 // argv[6]: timing only, no CSV
+    // the clocks of an idle GPU ramp up over the first milliseconds of work
+    const int warm = getenv("MVL_PROBE_WARMUP") ? atoi(getenv("MVL_PROBE_WARMUP")) : 0;
+    for (int rep = 0; rep < warm; ++rep)
+        if (launch_prefill<0, 128, false, false, true>(a, 0)) { fprintf(stderr, "launch failed\n"); return 1; }
+    CK(hipDeviceSynchronize());
     for (int rep = 0; rep < 5; ++rep) {      // the last launch's timestamps are the ones kept
         CK(hipEventRecord(e0, 0));
-        if (launch_prefill<0, 128, false>(a, 0)) { fprintf(stderr, "launch failed\n"); return 1; }
+        if (launch_prefill<0, 128, false, false, true>(a, 0)) { fprintf(stderr, "launch failed\n"); return 1; }
         CK(hipEventRecord(e1, 0));
         CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms, e0, e1));
         fprintf(stderr, "B=%d S=%d Hq=%d Hkv=%d: %.1f us\n", B, S, Hq, Hkv, ms * 1e3f);
     }
+    if (quiet) return 0;
     std::vector<unsigned long long> h((size_t)a.total_wg * 8);
     CK(hipMemcpy(h.data(), probe, h.size() * 8, hipMemcpyDeviceToHost));
     printf("wg,t_entry,t_first_tile,t_unmasked_done,t_end,n_tiles,hw_id,xcc_id\n");
