@@ -8,9 +8,10 @@
 // src/myvllm/layers/attention.py:111-280).  Design here:
 //
 //  * workgroup = 4 waves x 32 query rows (128-row Q tile), KV tiles of 64 rows; Q lives in
-//    registers for the whole kernel, K/V tiles are staged global -> registers -> LDS with the
-//    global loads issued one tile ahead (they fly under the MFMA work of the current tile)
-//    and block-table entries two tiles ahead;
+//    registers for the whole kernel, K/V tiles go global -> LDS by LDS-DMA into a double
+//    buffer, requested one tile ahead (they fly under the PV products of the current tile and
+//    the barrier that closes it) with the block-table entry read two tiles ahead; only an fp8
+//    cache is staged through registers (it has to be widened on the way);
 //  * S^T = K . Q^T on MFMA 32x32x16, so a lane owns one query row: the softmax row
 //    reduction is in-register plus one exchange between the two lane halves, and the
 //    accumulator is already the B operand of O^T = V^T . P^T (no LDS round trip for P);
@@ -369,7 +370,10 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     // maximum: it is only moved (and O, l rescaled) when some row's maximum outgrows it by
     // more than kRescaleThr (log2 units), so most tiles skip the O-wide rescale; P stays
     // <= 2^kRescaleThr, far inside bf16/fp16 range.
-    auto process_tile = [&](auto mask_tag, int kv0, const char* k_lds, const char* v_lds) {
+    // stage_late(): the request for the next tile, issued between the softmax and the PV
+    // products (UNI only; elsewhere a no-op and the request precedes the tile)
+    auto process_tile = [&](auto mask_tag, int kv0, const char* k_lds, const char* v_lds,
+                            auto&& stage_late) {
         constexpr bool MASK = decltype(mask_tag)::value;
         f32x16_t s_acc[2];
 #pragma unroll
@@ -431,6 +435,7 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
                 pfrag[sub][s] = __builtin_bit_cast(vec8, pack8<CODE>(p));
             }
         l_run += psum2[0] + psum2[1];
+        stage_late();
         if constexpr (!UNI) {
 #pragma unroll
             for (int n = 0; n < NDB; ++n) {
@@ -489,24 +494,33 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     // first query row need no mask; the last few (diagonal) tiles apply it.
     auto run_tiles = [&](auto mask_tag, int t_begin, int t_end) {
         for (int t = t_begin; t < t_end; ++t) {
-            if (t + 1 < n_tiles) {
-                // buffer (t+1)&1 was last read in iteration t-1; the barrier that closed it
-                // ordered those reads before this DMA (KV8: before the writes further down)
-                if constexpr (KV8) {
-                    load_tile8(t + 1, ids8_next, kraw, vraw);
-                    if (t + 2 < n_tiles) load_block_ids8(t + 2, ids8_next);
-                } else if constexpr (UNI) {
-                    stage_tile_uni(t + 1, blk_next);
-                    if (t + 2 < n_tiles) blk_next = tile_block(t + 2);
-                } else {
-                    stage_tile(t + 1, ids_next);
-                    if (t + 2 < n_tiles) load_block_ids(t + 2, ids_next);
-                }
-            }
             const int kv0 = t * kBN;
-            if (wave_live && kv0 <= wave_max_pos) {
+            const bool run = wave_live && kv0 <= wave_max_pos;
+            auto stage_next = [&]() {
+                if (t + 1 < n_tiles) {
+                    // buffer (t+1)&1 was last read in iteration t-1; the barrier that closed it
+                    // ordered those reads before this DMA (KV8: before the writes further down)
+                    if constexpr (KV8) {
+                        load_tile8(t + 1, ids8_next, kraw, vraw);
+                        if (t + 2 < n_tiles) load_block_ids8(t + 2, ids8_next);
+                    } else if constexpr (UNI) {
+                        stage_tile_uni(t + 1, blk_next);
+                        if (t + 2 < n_tiles) blk_next = tile_block(t + 2);
+                    } else {
+                        stage_tile(t + 1, ids_next);
+                        if (t + 2 < n_tiles) load_block_ids(t + 2, ids_next);
+                    }
+                }
+            };
+            // UNI: a wave that runs the tile issues its requests after the tile's softmax, where
+            // they share their issue slots with vector-ALU work only; next to the 16 K fragment
+            // reads at the top of the tile they cost more (2-3 % of the kernel at >= 4k tokens).
+            // They still have the PV products and the barrier's wait to land.
+            if (!UNI || !run) stage_next();
+            if (run) {
                 const char* k_lds = smem + (t & 1) * (2 * TILE_BYTES);
-                process_tile(mask_tag, kv0, k_lds, k_lds + TILE_BYTES);
+                if constexpr (UNI) process_tile(mask_tag, kv0, k_lds, k_lds + TILE_BYTES, stage_next);
+                else process_tile(mask_tag, kv0, k_lds, k_lds + TILE_BYTES, []() {});
             }
             if (t + 1 < n_tiles) {
                 if constexpr (KV8) write_tile8(t + 1, kraw, vraw);
