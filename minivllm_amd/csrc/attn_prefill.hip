@@ -536,18 +536,30 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 
     // ---- epilogue: O[q][d] = O^T / l --------------------------------------------------
     l_run += __shfl_xor(l_run, 32, 64);
-    if (my_q < q_len) {
+    {
+        // A row's 8 d-values of group k = 4 n + g8 are split over the two lane halves (4 + 4), so
+        // the natural store is 8 bytes per lane.  One half exchange per dword between groups k
+        // and k + 1 (v_permlane32_swap: the upper half of the first operand swaps with the lower
+        // half of the second) leaves the lower lanes with the 16 contiguous bytes of group k and
+        // the upper lanes with those of group k + 1: half as many store instructions for the
+        // same bytes (the tail of a workgroup is bound by the issue of its stores).
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
-        uint16_t* op = a.out + (long)(q_start + my_q) * a.o_stride_t + (long)head * a.o_stride_h;
+        const bool live = my_q < q_len;
+        uint16_t* op = a.out + (long)(q_start + (live ? my_q : 0)) * a.o_stride_t + (long)head * a.o_stride_h
+                       + 8 * hh;
 #pragma unroll
         for (int n = 0; n < NDB; ++n)
 #pragma unroll
-            for (int g8 = 0; g8 < 4; ++g8) {
+            for (int g8 = 0; g8 < 4; g8 += 2) {
                 // registers 4 g8 .. 4 g8 + 3 are d = 32 n + 8 g8 + 4 hh + (0..3)
-                u32x2_t o;
-                o[0] = pack2<CODE>(acc_o[n][4 * g8 + 0] * inv, acc_o[n][4 * g8 + 1] * inv);
-                o[1] = pack2<CODE>(acc_o[n][4 * g8 + 2] * inv, acc_o[n][4 * g8 + 3] * inv);
-                *reinterpret_cast<u32x2_t*>(op + 32 * n + 8 * g8 + 4 * hh) = o;
+                uint32_t ax = pack2<CODE>(acc_o[n][4 * g8 + 0] * inv, acc_o[n][4 * g8 + 1] * inv);
+                uint32_t ay = pack2<CODE>(acc_o[n][4 * g8 + 2] * inv, acc_o[n][4 * g8 + 3] * inv);
+                uint32_t bx = pack2<CODE>(acc_o[n][4 * g8 + 4] * inv, acc_o[n][4 * g8 + 5] * inv);
+                uint32_t by = pack2<CODE>(acc_o[n][4 * g8 + 6] * inv, acc_o[n][4 * g8 + 7] * inv);
+                const auto rx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+                const auto ry = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+                if (live)
+                    *reinterpret_cast<u32x4_t*>(op + 32 * n + 8 * g8) = u32x4_t{rx[0], ry[0], rx[1], ry[1]};
             }
     }
     }   // pass
@@ -578,6 +590,8 @@ extern "C" int mvl_flash_attention_prefill(
     if ((D != 64 && D != 128) || Hq % Hkv != 0) return -1;
     if (paged && (block_size & (block_size - 1))) return -1;
     if (kv_fp8 && !paged) return -1;
+    // the output is written 16 bytes at a time
+    if (((uintptr_t)out & 15) || (o_stride_t & 7) || (o_stride_h & 7)) return -1;
     PrefillArgs a;
     a.q = (const uint16_t*)q; a.q_stride_t = q_stride_t; a.q_stride_h = q_stride_h;
     a.k = (const uint16_t*)k; a.v = (const uint16_t*)v;
