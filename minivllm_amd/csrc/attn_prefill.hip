@@ -155,6 +155,23 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
             qfrag[s] = __builtin_bit_cast(vec8, *reinterpret_cast<const u32x4_t*>(qp + 16 * s + 8 * hh));
     }
     const int my_pos = my_q + pos_off;                   // last key this row may see
+    // fused Q transform: the row's position, requested with the Q loads (its table row follows
+    // the first tile's DMA)
+    // (an unconditional load from an address that is always valid: a conditional one would be
+    // waited for where its branch ends, ahead of the first tile's requests)
+    const int my_rope_pos = *(a.cos_sin != nullptr ? a.positions + (q_start + my_q_c) : a.cu_q);
+    // the norm weights of the lane's 8-blocks, requested here for the same reason (256 bytes that
+    // every workgroup reads: cache hits); without a weight the Q row itself stands in, unused
+    u32x4_t qw_raw[KSTEPS];
+    {
+        const uint16_t* wp = a.q_w != nullptr
+            ? a.q_w : a.q + (long)(q_start + my_q_c) * a.q_stride_t + (long)head * a.q_stride_h;
+        if (a.cos_sin != nullptr) {
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s)
+                qw_raw[s] = *reinterpret_cast<const u32x4_t*>(wp + 16 * s + 8 * hh);
+        }
+    }
     const int wave_min_pos = q0 + 32 * w + pos_off;
     const int wave_max_pos = min(q0 + 32 * w + 31, q_len - 1) + pos_off;
     const bool wave_live = q0 + 32 * w < q_len;
@@ -282,20 +299,6 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc_o[n][e] = 0.f;
 
-    // fused Q transform: the rotary table row of the lane's query is requested here, ahead of
-    // the first tile
-    f32x4_t cs_raw[KSTEPS / 2][4];
-    if (a.cos_sin != nullptr) {
-        const float* cs = a.cos_sin + (long)a.positions[q_start + my_q_c] * D;
-#pragma unroll
-        for (int s = 0; s < KSTEPS / 2; ++s) {
-            cs_raw[s][0] = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh);
-            cs_raw[s][1] = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh + 4);
-            cs_raw[s][2] = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh);
-            cs_raw[s][3] = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh + 4);
-        }
-    }
-
     int ids_next[ITER];
     int ids8_next[ITER8 > 0 ? ITER8 : 1];
     u32x4_t kraw[ITER8 > 0 ? ITER8 : 1], vraw[ITER8 > 0 ? ITER8 : 1];
@@ -313,43 +316,66 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
         stage_tile(0, ids);
         if (n_tiles > 1) load_block_ids(1, ids_next);
     }
+    // nothing that waits for a load (the table address needs the row's position) moves above
+    // the first tile's requests
+    __builtin_amdgcn_sched_barrier(0);
     // ---- q-norm + RoPE of the Q rows, fused here: a Q row is read by exactly one workgroup,
     //      so the projection's output never has to be rewritten in place and read again (K is
     //      shared by many workgroups and is transformed by the store kernel beforehand).  Pairs
     //      (e, e + D/2) of a row sit in one lane: fragments s and s + KSTEPS/2.  The table row
     //      was requested before the first tile's DMA; the arithmetic runs in that DMA's shadow.
     if (a.cos_sin != nullptr) {
-        float f[KSTEPS][8];
+        // the rotary table row of the lane's query: requested here, after the first tile's DMA,
+        // where few other values are live (requested earlier, the 64 registers were spilled one
+        // load at a time, each behind its own vmcnt(0)); the sum of squares below covers part
+        // of the latency
+        f32x4_t cs_raw[KSTEPS / 2][4];
+        {
+            const float* cs = a.cos_sin + (long)my_rope_pos * D;
+#pragma unroll
+            for (int s = 0; s < KSTEPS / 2; ++s) {
+                cs_raw[s][0] = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh);
+                cs_raw[s][1] = *reinterpret_cast<const f32x4_t*>(cs + 16 * s + 8 * hh + 4);
+                cs_raw[s][2] = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh);
+                cs_raw[s][3] = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 16 * s + 8 * hh + 4);
+            }
+        }
+        // two passes over the packed fragments (sum of squares, then scale + rotate one pair of
+        // fragments at a time) instead of one over an unpacked fp32 copy of the row: with the
+        // 64 table registers in flight that copy did not fit, and the compiler spilled the
+        // table loads one by one, each behind its own vmcnt(0)
         float ss = 0.f;
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
-            unpack8<CODE>(__builtin_bit_cast(u32x4_t, qfrag[s]), f[s]);
+            float f[8];
+            unpack8<CODE>(__builtin_bit_cast(u32x4_t, qfrag[s]), f);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) ss += f[s][i] * f[s][i];
+            for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
         }
         ss += __shfl_xor(ss, 32, 64);                    // the other half of the row
-        if (a.q_w != nullptr) {
-            const float rstd = rsqrtf(ss / (float)D + a.eps);
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                float wv[8];
-                unpack8<CODE>(*reinterpret_cast<const u32x4_t*>(a.q_w + 16 * s + 8 * hh), wv);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) f[s][i] *= rstd * wv[i];
-            }
-        }
+        const float rstd = a.q_w != nullptr ? rsqrtf(ss / (float)D + a.eps) : 1.f;
 #pragma unroll
         for (int s = 0; s < KSTEPS / 2; ++s) {
+            float f1[8], f2[8];
+            unpack8<CODE>(__builtin_bit_cast(u32x4_t, qfrag[s]), f1);
+            unpack8<CODE>(__builtin_bit_cast(u32x4_t, qfrag[s + KSTEPS / 2]), f2);
+            if (a.q_w != nullptr) {
+                float w1[8], w2[8];
+                unpack8<CODE>(qw_raw[s], w1);
+                unpack8<CODE>(qw_raw[s + KSTEPS / 2], w2);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { f1[i] *= rstd * w1[i]; f2[i] *= rstd * w2[i]; }
+            }
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float c = cs_raw[s][i >> 2][i & 3], sn = cs_raw[s][2 + (i >> 2)][i & 3];
-                const float x1 = f[s][i], x2 = f[s + KSTEPS / 2][i];
-                f[s][i] = x1 * c - x2 * sn;
-                f[s + KSTEPS / 2][i] = x1 * sn + x2 * c;
+                const float x1 = f1[i], x2 = f2[i];
+                f1[i] = x1 * c - x2 * sn;
+                f2[i] = x1 * sn + x2 * c;
             }
+            qfrag[s] = __builtin_bit_cast(vec8, pack8<CODE>(f1));
+            qfrag[s + KSTEPS / 2] = __builtin_bit_cast(vec8, pack8<CODE>(f2));
         }
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) qfrag[s] = __builtin_bit_cast(vec8, pack8<CODE>(f[s]));
     }
     if constexpr (KV8) write_tile8(0, kraw, vraw);
     __syncthreads();                         // drains the LDS-DMA (vmcnt) and meets the waves
