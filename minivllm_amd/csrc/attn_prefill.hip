@@ -32,6 +32,16 @@ typedef __attribute__((ext_vector_type(8))) short s16x8_t;
 
 namespace {
 
+// f(integral_constant<int, I>) for I = FIRST .. LAST - 1: loop indices that stay constant expressions
+// (immediate operands of inline asm)
+template <int FIRST, int LAST, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (FIRST < LAST) {
+        f(std::integral_constant<int, FIRST>{});
+        static_for<FIRST + 1, LAST>(f);
+    }
+}
+
 constexpr int kBM = 128;           // query rows per workgroup
 constexpr int kBN = 64;            // kv rows per tile
 constexpr int kThreads = 256;
@@ -390,6 +400,15 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     const int tr_row0 = 4 * hh + (i16 >> 2);
     const int tr_chunk0 = 2 * ((lane >> 4) & 1) + ((i16 & 3) >> 1);
     const int tr_sub = (i16 & 1) * 8;
+    // LDS offsets of the lane's V fragments inside a {K, V} buffer, for d block n and the two
+    // 8-row halves of a k-slot group; the 16 (s) and 32 (sub) row steps leave the swizzle term
+    // unchanged and go into the reads' immediate offsets
+    int v_frag_off[NDB][2];
+#pragma unroll
+    for (int n = 0; n < NDB; ++n)
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi)
+            v_frag_off[n][hi] = TILE_BYTES + tile_off<CPR>(tr_row0 + 8 * hi, 4 * n + tr_chunk0) + tr_sub;
 
     // One KV tile for this wave: S^T = K.Q^T, online softmax, O^T += V^T.P^T.
     // m_run is the reference point of the exponentials, not necessarily the true row
@@ -486,32 +505,38 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
             // of step i + 2 are requested before step i's MFMA, and LDS returns in order, so "at
             // most 4 outstanding" means the pair of step i has arrived.
             constexpr int NPV = 4 * NDB;
-            const uint32_t v_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)v_lds;
-            s16x4_t vlo[NPV], vhi[NPV];
-            auto v_read = [&](int i) {
-                const int n = i / 4, sub = (i >> 1) & 1, s = i & 1;
-                const int row = 32 * sub + 16 * s + tr_row0;
-                const int ch = 4 * n + tr_chunk0;
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vlo[i])
-                             : "v"(v_base + tile_off<CPR>(row, ch) + tr_sub));
-                asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(vhi[i])
-                             : "v"(v_base + tile_off<CPR>(row + 8, ch) + tr_sub));
-            };
-            v_read(0);
-            v_read(1);
+            const uint32_t kb32 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)k_lds;
+            uint32_t va[NDB][2];
 #pragma unroll
-            for (int i = 0; i < NPV; ++i) {
-                if (i + 2 < NPV) {
-                    v_read(i + 2);
-                    asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(vlo[i]), "+v"(vhi[i]));
-                } else if (i + 1 < NPV) {
-                    asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(vlo[i]), "+v"(vhi[i]));
-                } else {
-                    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(vlo[i]), "+v"(vhi[i]));
-                }
-                const s16x8_t av = __builtin_shufflevector(vlo[i], vhi[i], 0, 1, 2, 3, 4, 5, 6, 7);
-                acc_o[i / 4] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[(i >> 1) & 1][i & 1], acc_o[i / 4]);
+            for (int n = 0; n < NDB; ++n) {
+                va[n][0] = kb32 + v_frag_off[n][0];
+                va[n][1] = kb32 + v_frag_off[n][1];
             }
+            s16x4_t vlo[NPV], vhi[NPV];
+            auto v_read = [&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                constexpr int n = i / 4, sub = (i >> 1) & 1, s = i & 1;
+                constexpr int off = (32 * sub + 16 * s) * CPR * 16;
+                // (asm operands do not count as uses that capture: go through named locals)
+                const uint32_t a0 = va[n][0], a1 = va[n][1];
+                s16x4_t lo, hi;
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(off));
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(off));
+                vlo[i] = lo;
+                vhi[i] = hi;
+            };
+            v_read(std::integral_constant<int, 0>{});
+            v_read(std::integral_constant<int, 1>{});
+            static_for<0, NPV>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                if constexpr (i + 2 < NPV) v_read(std::integral_constant<int, i + 2>{});
+                s16x4_t lo = vlo[i], hi = vhi[i];
+                if constexpr (i + 2 < NPV) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(lo), "+v"(hi));
+                else if constexpr (i + 1 < NPV) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(lo), "+v"(hi));
+                else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo), "+v"(hi));
+                const s16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc_o[i / 4] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[(i >> 1) & 1][i & 1], acc_o[i / 4]);
+            });
         }
     };
 
