@@ -401,6 +401,30 @@ def test_flash_prefill_strided_qkv(hip):
     close(got, want, dtype)
 
 
+def test_paged_prefill_output_views(hip):
+    """The kernel stores 16 bytes per lane: an output that is a row-strided view of a wider
+    buffer is fine as long as every row starts on a 16-byte boundary; one that does not is
+    refused instead of written with misaligned stores."""
+    torch.manual_seed(12)
+    dtype, hq, hkv, d, bs = torch.bfloat16, 16, 8, 128, 64
+    lens = [130, 70]
+    T = sum(lens)
+    q = torch.randn(T, hq, d, device=DEV, dtype=dtype)
+    kk = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    vv = torch.randn(T, hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(kk, vv, lens, bs, hkv, d, dtype)
+    cu = torch.tensor([0, 130, 200], device=DEV, dtype=torch.int32)
+    want = ref.paged_attention_prefill(q, kc, vc, cu, cu, tables, 0.088)
+    wide = torch.zeros(T, hq * d + 64, device=DEV, dtype=dtype)
+    out = wide[:, 32:32 + hq * d].view(T, hq, d)          # rows 64 bytes into a wider pitch
+    hip.paged_attention_prefill(q, kc, vc, cu, cu, tables, 0.088, out=out)
+    close(out, want, dtype)
+    assert not wide[:, :32].any() and not wide[:, 32 + hq * d:].any()
+    bad = wide[:, 4:4 + hq * d].view(T, hq, d)            # rows start 8 bytes off
+    with pytest.raises(RuntimeError):
+        hip.paged_attention_prefill(q, kc, vc, cu, cu, tables, 0.088, out=bad)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("bs", [16, 256])
 @pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (16, 8, 64)])
