@@ -481,23 +481,7 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
             }
         l_run += psum2[0] + psum2[1];
         stage_late();
-        if constexpr (!UNI) {
-#pragma unroll
-            for (int n = 0; n < NDB; ++n) {
-#pragma unroll
-                for (int sub = 0; sub < 2; ++sub)
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        // k-slot j of lane half hh <-> key 32 sub + 16 s + 8 (j>>2) + 4 hh + (j&3)
-                        const int row = 32 * sub + 16 * s + tr_row0;
-                        const int ch = 4 * n + tr_chunk0;
-                        const s16x4_t lo = lds_read_tr16(v_lds, tile_off<CPR>(row, ch) + tr_sub);
-                        const s16x4_t hi = lds_read_tr16(v_lds, tile_off<CPR>(row + 8, ch) + tr_sub);
-                        const s16x8_t av = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                        acc_o[n] = DT::mfma32(__builtin_bit_cast(vec8, av), pfrag[sub][s], acc_o[n]);
-                    }
-            }
-        } else {
+        {
             // Through the builtin the compiler waits for EVERY LDS-DMA request in flight
             // (vmcnt(0)) before the first transposed read, i.e. for the next tile, requested at
             // the top of this iteration and needed only after its closing barrier.  As inline asm
