@@ -648,11 +648,12 @@ extern "C" int mvl_flash_attention_prefill(
     a.B = B; a.Hq = Hq; a.Hkv = Hkv;
     a.n_qtiles = (max_q_len + kBM - 1) / kBM;
     static const char* pair_env = getenv("MVL_PREFILL_PAIR");
-    // pairs per workgroup: as many (1, 2 or 4) as still leave two workgroups per CU
-    int group = 4;
+    // one heavy / light pair per workgroup (MVL_PREFILL_PAIR: 0 = one Q tile per workgroup, g = g
+    // pairs).  Several pairs per workgroup once paid for the workgroup's fixed cost; since the
+    // prologue got short, more and smaller workgroups balance better (32 x 512, 16 q heads:
+    // 0.073 ms with two pairs, 0.068 ms with one)
     const int n_pairs = (a.n_qtiles + 1) / 2;
-    while (group > 1 && (long)B * Hq * ((n_pairs + group - 1) / group) < 512) group >>= 1;
-    a.pair = pair_env ? atoi(pair_env) : group;
+    a.pair = pair_env ? atoi(pair_env) : 1;
     a.n_items = a.pair ? (n_pairs + a.pair - 1) / a.pair : a.n_qtiles;
     a.total_wg = B * Hq * a.n_items;
     if (cos_sin != nullptr && positions == nullptr) return -1;
