@@ -57,7 +57,7 @@ int main(int argc, char** argv) {
     // default: one Q tile per workgroup (the stamps are per tile count); argv[5] = pairs per workgroup
     a.pair = argc > 5 ? atoi(argv[5]) : 0;
     a.n_items = a.pair ? ((a.n_qtiles + 1) / 2 + a.pair - 1) / a.pair : a.n_qtiles;
-    a.total_wg = B * Hq * a.n_qtiles;
+    a.total_wg = B * Hq * a.n_items;
     CK(hipMalloc(&probe, (size_t)a.total_wg * 8 * 8));
     CK(hipMemset(probe, 0, (size_t)a.total_wg * 8 * 8));
     a.probe = probe;
