@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 import torch
 
-pytestmark = pytest.mark.gpu
+# never run on real links so far: a bounded wait, so that a hang there fails one test and not the run
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(900)]
 
 
 def _need(n):
