@@ -72,7 +72,38 @@ def make_config(args, model_name: str, world: int) -> EngineConfig:
         master_addr=os.environ.get("MASTER_ADDR", "127.0.0.1"), master_port=port,
         # MINIVLLM_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal only)
         dist_backend=os.environ.get("MINIVLLM_DIST_BACKEND", "auto"),
-        max_cached_blocks=args.kv_blocks, kv_cache_dtype=args.kv_cache_dtype).validate()
+        max_cached_blocks=args.kv_blocks, kv_cache_dtype=args.kv_cache_dtype,
+        tp_shard=args.tp_shard if world == 1 else 0,
+        custom_all_reduce=bool(args.tp_shard and args.p2p)).validate()
+
+
+def gpu_state() -> dict:
+    """Clock / power readings of GPU 0 as the SMI tools report them, so that a slow number can be
+    told from a slow box (boxes of one pool differ by 5-15 %).  Best effort: absent tools or
+    fields simply leave entries out."""
+    import shutil
+    out = {}
+    try:
+        out["device"] = torch.cuda.get_device_name(0)
+        out["cu_count"] = torch.cuda.get_device_properties(0).multi_processor_count
+    except Exception:
+        pass
+    for tool, argv in (("amd-smi", ["amd-smi", "metric", "-g", "0", "--clock", "--power", "--json"]),
+                       ("rocm-smi", ["rocm-smi", "-d", "0", "--showclocks", "--showpower",
+                                     "--showmaxpower", "--showperflevel", "--json"])):
+        if not shutil.which(argv[0]):
+            continue
+        try:
+            r = subprocess.run(argv, capture_output=True, text=True, timeout=20)
+            if r.returncode == 0 and r.stdout.strip():
+                try:
+                    out[tool] = json.loads(r.stdout)
+                except ValueError:
+                    out[tool] = r.stdout.strip()[:1500]
+                break
+        except Exception:
+            continue
+    return out
 
 
 class _ReplicaTimer:
@@ -129,7 +160,12 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
         return rng.integers(0, vocab, size=(n, length)).tolist()
 
     res = {"init_s": round(init_s, 1), "kv_blocks": eng.model_runner.num_kv_blocks,
-           "hipgraph_captured": bool(eng.model_runner.graphs)}
+           "hipgraph_captured": bool(eng.model_runner.graphs),
+           "gemm_choice_source": getattr(eng.model_runner, "gemm_choice_source", None),
+           "gemm_choices": getattr(eng.model_runner, "gemm_choices", None)}
+    if cfg.tp_shard:
+        from minivllm_amd.parallel import group as pg
+        res["p2p_allreduce"] = pg.custom_all_reduce() is not None
     if not replicas:
         from minivllm_amd.parallel import group as pg
         res["tp_world_size_seen"] = (dist.get_world_size(pg.tp_group())
@@ -169,6 +205,9 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
         for _ in range(W):
             _, n, is_prefill = eng.step()
             assert not is_prefill and n == B
+        # with launch-ahead decode one step is already in flight here and another one is when the
+        # timed loop ends: timer_start / timer_stop drain the device, so the K timed steps contain
+        # exactly K steps of GPU work (one carried in, one carried out)
         runner.call("timer_start")
         tokens = 0
         for _ in range(K):
@@ -399,6 +438,12 @@ def main():
                     help="with N > 1, skip the TP phase that uses the peer-to-peer all-reduce kernel")
     ap.add_argument("--phase-timeout", type=int, default=600,
                     help="time limit in seconds of one phase (N > 1)")
+    ap.add_argument("--tp-shard", type=int, default=0,
+                    help="ONE GPU: run rank 0's shard of an N-way tensor-parallel engine with every "
+                         "collective issued through a single-member RCCL group (per-rank compute + "
+                         "launch floor of a real N-GPU run; NOT a scaling number)")
+    ap.add_argument("--p2p", action="store_true",
+                    help="with --tp-shard: all-reduces by the peer-to-peer kernels in loop-back form")
     args = ap.parse_args()
 
     if os.environ.get("MINIVLLM_HANG_DUMP"):     # debugging aid: dump all stacks if stuck
@@ -435,8 +480,16 @@ def main():
         res = run_phase(args, "single", rank, local_rank, world)
         m, second = res["main"], res["second"]
         value, ms = headline(m)
+        par = "tp1"
+        if args.tp_shard > 1:
+            par = f"ONE rank's shard of tp{args.tp_shard}, no peers (rehearsal)"
+            metric = (f"REHEARSAL, not a throughput: step time of one rank of a tp{args.tp_shard} "
+                      f"engine with nobody at the other end of its collectives ({args.model})")
+            base = dict(base, n_gpus=1, rehearsal=True,
+                        all_reduce="p2p kernels, loop-back" if args.p2p else "rccl, single-member group")
         out = {"metric": metric, "value": value, **base, "ms_per_step": ms, "scaling": "weak",
-               "config": {**cfg_common, "global_batch": B, "parallelism": "tp1"}, **_round(m),
+               "config": {**cfg_common, "global_batch": B, "parallelism": par}, **_round(m),
+               "gpu_state": gpu_state(),
                "published_reference_check": published_reference_check()}
         if second is not None:
             out["secondary"] = {"model": args.second_model, **_round(second)}

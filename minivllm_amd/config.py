@@ -170,6 +170,12 @@ class EngineConfig:
     # the SwiGLU epilogue for gate_up) against the library (+ activation kernel) on this model's
     # projections at prefill-sized row counts and use whichever is faster per shape and row bucket
     tune_prefill_gemms: bool = True
+    # where the outcome of those start-up measurements is kept, so that a second start of the
+    # same engine on the same GPU type loads the table instead of timing again (same kernels,
+    # hence the same roundings, from one start to the next): a JSON file, "auto" =
+    # ~/.cache/minivllm_amd/gemm_choices.json (env MINIVLLM_GEMM_CHOICES overrides), "" = off.
+    # Under tensor parallelism rank 0's table is what every rank uses.
+    gemm_choice_cache: str = "auto"
     # GPU only, experimental: multiply each layer norm's scale vector into the weights of the
     # projection behind it at load time, which lets 1-2 row decode batches run (residual add +
     # norm + projection) as one kernel (csrc/skinny_norm_gemm.hip).  Measured on Qwen3-8B: 3.93
@@ -215,6 +221,14 @@ class EngineConfig:
     # testing aid: with world_size 1 still create a (single-rank) process group and run every
     # tensor-parallel collective through it, graph capture included
     force_tp_group: bool = False
+    # shard rehearsal (measurement aid, one process, one GPU): build rank ``tp_shard_rank``'s
+    # shard of a ``tp_shard``-way tensor-parallel engine - per-rank weight shapes, per-rank KV
+    # heads, every collective issued through a single-member process group (real RCCL nodes
+    # inside the decode graphs, nobody at the other end).  A step then costs what ONE rank of the
+    # sharded engine computes and launches: the floor under the step time of a real N-GPU run.
+    # Generated tokens are meaningless (partial sums are never completed).  0 = off.
+    tp_shard: int = 0
+    tp_shard_rank: int = 0
     # number of engine replicas behind engine.dp_engine.DataParallelEngine (1 = none)
     data_parallel_size: int = 1
 
@@ -224,18 +238,28 @@ class EngineConfig:
             return "cuda" if torch.cuda.is_available() else "cpu"
         return self.device
 
+    @property
+    def tp_degree(self) -> int:
+        """Number of ways the model is sharded (= world_size, or ``tp_shard`` in a rehearsal)."""
+        return self.tp_shard if self.tp_shard > 1 else self.world_size
+
     def validate(self) -> "EngineConfig":
         m = self.model
+        if self.tp_shard > 1 and self.world_size != 1:
+            raise ValueError("tp_shard rehearses ONE rank of a sharded engine: world_size must be 1")
+        if self.tp_shard > 1 and not (0 <= self.tp_shard_rank < self.tp_shard):
+            raise ValueError("tp_shard_rank must be in [0, tp_shard)")
         if self.block_size <= 0 or (self.block_size & (self.block_size - 1)):
             raise ValueError(f"block_size must be a power of two, got {self.block_size}")
         if m.num_heads % m.num_kv_heads:
             raise ValueError("num_heads must be a multiple of num_kv_heads")
-        if m.num_heads % self.world_size or m.num_kv_heads % self.world_size:
+        tp = self.tp_degree
+        if m.num_heads % tp or m.num_kv_heads % tp:
             raise ValueError(
-                f"world_size={self.world_size} must divide num_heads={m.num_heads} and "
+                f"tensor-parallel degree {tp} must divide num_heads={m.num_heads} and "
                 f"num_kv_heads={m.num_kv_heads} (KV-head replication is not supported)")
-        if m.intermediate_size % self.world_size:
-            raise ValueError("world_size must divide intermediate_size")
+        if m.intermediate_size % tp:
+            raise ValueError("the tensor-parallel degree must divide intermediate_size")
         if m.head_dim not in (64, 128) and self.resolved_device() == "cuda":
             raise ValueError("HIP attention kernels support head_dim 64 and 128")
         if self.max_model_length > m.max_position:

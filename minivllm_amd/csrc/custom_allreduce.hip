@@ -14,6 +14,16 @@
 //                      stores the new residual and writes the RMS-normalised row - the
 //                      (residual add + RMSNorm) kernel that follows every row-parallel
 //                      projection of a decoder layer disappears for decode-sized batches
+//   two-shot + norm:   the same fusion for messages above the one-shot size (a 256-row decode
+//                      batch is 2 MB): rank r owns rows [r R, (r + 1) R) of the residual stream
+//                      (R = rows / P), reduces exactly those rows from all ranks' staging, adds
+//                      ITS slice of the residual, stores it, normalises and publishes the
+//                      normalised rows; the ranks then gather each other's normalised rows.  The
+//                      residual stream stays row-sharded between the two norms of a layer and
+//                      between layers, so only normalised rows ever cross the links a second time
+//                      (2 (P-1)/P of the message per rank, as a plain two-shot all-reduce)
+//   Both fused forms can take the producing GEMM's not yet summed fp32 K-slice partials instead
+//   of its output: the slices are summed while the rows are staged.
 //
 // Two-shot moves 2 (P-1)/P of the message over each rank's links (like reduce-scatter +
 // all-gather), one-shot (P-1) times the message but with one barrier less.
@@ -53,6 +63,10 @@ struct Peers {
     uint16_t* stage[kMaxRanks];                // inputs, one buffer per rank
     uint16_t* result[kMaxRanks];               // reduced slices (two-shot)
     long timeout_ticks;                        // longest wait for a peer, in 10 ns ticks
+    // Rehearsal of one rank of a P-way group on a single GPU: every table entry is this rank's
+    // own allocation and lane p of a barrier plays peer p (it raises the flag that peer would
+    // raise).  Data paths, flag traffic and fences are those of the real thing; the sums are not.
+    int loopback;
 };
 
 long g_timeout_ticks = kDefaultTimeoutTicks;
@@ -77,7 +91,8 @@ __device__ __forceinline__ bool block_barrier(const Peers& pr, int rank, int pha
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");             // system scope: write back
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __hip_atomic_store(&pr.flags[threadIdx.x]->counter[phase][blockIdx.x][rank], epoch,
+        const int slot = pr.loopback ? (int)threadIdx.x : rank;
+        __hip_atomic_store(&pr.flags[threadIdx.x]->counter[phase][blockIdx.x][slot], epoch,
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const long t0 = (long)__builtin_amdgcn_s_memrealtime();
         int spins = 0;
@@ -170,20 +185,70 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank
     if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
 }
 
-// One-shot all-reduce of x [rows, hidden] fused with `r = sum + residual; residual = r;
-// x = rms_norm(r) * gamma`.  Block b owns rows b, b + gridDim.x, ...  Rounding points and the
+// What a rank contributes to a fused reduce + norm: its [rows, hidden] partial sums in the
+// storage dtype, or the not yet summed fp32 K-slice partials [S][rows][hidden] of the GEMM that
+// produced them (summed in slice order and rounded once, exactly as the stand-alone partial-sum
+// kernel of mid_gemm.hip does, so both routes stage the same bits).
+struct RowSource {
+    const uint16_t* x;
+    const float* parts;                        // nullptr: take x
+    int nparts;
+    long slab;                                 // rows * hidden
+};
+
+template <int CODE>
+__device__ __forceinline__ u32x4_t load_chunk(const RowSource& s, long at) {
+    if (s.parts == nullptr) return reinterpret_cast<const u32x4_t*>(s.x)[at];
+    const float* p = s.parts + at * 8;
+    f32x4_t lo = *reinterpret_cast<const f32x4_t*>(p);
+    f32x4_t hi = *reinterpret_cast<const f32x4_t*>(p + 4);
+    for (int k = 1; k < s.nparts; ++k) {
+        lo += *reinterpret_cast<const f32x4_t*>(p + k * s.slab);
+        hi += *reinterpret_cast<const f32x4_t*>(p + k * s.slab + 4);
+    }
+    const float f[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return pack8<CODE>(f);
+}
+
+// Sum over the P staging buffers of chunk `at` (rank order: same bits on every rank), rounded as
+// the all-reduce rounds; + residual chunk, rounded as the add + norm kernel rounds.  Returns the
+// chunk's share of the sum of squares.
+template <int CODE, int P>
+__device__ __forceinline__ float reduce_add_chunk(const Peers& pr, long at, u32x4_t* res_chunk,
+                                                  float (&v)[8]) {
+    u32x4_t pv[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) pv[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[at];
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < P; ++p) accumulate<CODE>(acc, pv[p]);
+    unpack8<CODE>(pack8<CODE>(acc), v);                     // the all-reduce's rounding
+    float r[8];
+    unpack8<CODE>(*res_chunk, r);
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = DType<CODE>::to_float(DType<CODE>::from_float(v[j] + r[j]));
+        ss += v[j] * v[j];
+    }
+    *res_chunk = pack8<CODE>(v);
+    return ss;
+}
+
+// One-shot all-reduce of [rows, hidden] fused with `r = sum + residual; residual = r;
+// out = rms_norm(r) * gamma`.  Block b owns rows b, b + gridDim.x, ...  Rounding points and the
 // order of the sum of squares are those of the stand-alone kernels (all-reduce result rounded
 // to the storage dtype, then elementwise.hip's add + norm with the same thread <-> chunk
 // mapping), so both routes give the same bits.
 template <int CODE, int P, int MAXC>
 __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
-        Peers pr, int rank, uint16_t* __restrict__ x, uint16_t* __restrict__ residual,
+        Peers pr, int rank, RowSource src, uint16_t* __restrict__ out, uint16_t* __restrict__ residual,
         const uint16_t* __restrict__ gamma, int rows, int hidden, float eps) {
     __shared__ float scratch[16];
     Flags* mine = pr.flags[rank];
     const uint32_t epoch = mine->epoch[blockIdx.x] + 1;
     const int nchunk = hidden >> 3;
-    u32x4_t* xv = reinterpret_cast<u32x4_t*>(x);
+    u32x4_t* ov = reinterpret_cast<u32x4_t*>(out);
     u32x4_t* rv = reinterpret_cast<u32x4_t*>(residual);
     u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
 
@@ -191,14 +256,14 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = threadIdx.x + i * blockDim.x;
-            if (c < nchunk) st[(long)row * nchunk + c] = xv[(long)row * nchunk + c];
+            if (c < nchunk) st[(long)row * nchunk + c] = load_chunk<CODE>(src, (long)row * nchunk + c);
         }
     if (!block_barrier<P>(pr, rank, 0, epoch, true)) {
         for (int row = blockIdx.x; row < rows; row += gridDim.x)
 #pragma unroll
             for (int i = 0; i < MAXC; ++i) {
                 const int c = threadIdx.x + i * blockDim.x;
-                if (c < nchunk) xv[(long)row * nchunk + c] = nan_vec<CODE>();
+                if (c < nchunk) ov[(long)row * nchunk + c] = nan_vec<CODE>();
             }
         if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
         return;
@@ -213,22 +278,7 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
             const int c = threadIdx.x + i * blockDim.x;
             if (c < nchunk) {
                 const long at = (long)row * nchunk + c;
-                u32x4_t pv[P];
-#pragma unroll
-                for (int p = 0; p < P; ++p)
-                    pv[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[at];
-                float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int p = 0; p < P; ++p) accumulate<CODE>(acc, pv[p]);
-                unpack8<CODE>(pack8<CODE>(acc), v[i]);          // the all-reduce's rounding
-                float r[8];
-                unpack8<CODE>(rv[at], r);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[i][j] = DType<CODE>::to_float(DType<CODE>::from_float(v[i][j] + r[j]));
-                rv[at] = pack8<CODE>(v[i]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) ss += v[i][j] * v[i][j];
+                ss += reduce_add_chunk<CODE, P>(pr, at, rv + at, v[i]);
             }
         }
         ss = block_sum(ss, scratch);
@@ -241,7 +291,7 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
                 unpack8<CODE>(wr[c], w);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) o[j] = v[i][j] * rstd * w[j];
-                xv[(long)row * nchunk + c] = pack8<CODE>(o);
+                ov[(long)row * nchunk + c] = pack8<CODE>(o);
             }
         }
     }
@@ -249,33 +299,125 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
     if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
 }
 
+// Two-shot form with a row-sharded residual stream: `residual` is THIS rank's [rows / P, hidden]
+// slice (rows rank R .. rank R + R - 1 of the stream).  Block b handles local rows j = b,
+// b + gridDim.x, ... of EVERY slice in the staging and gather phases, so a block still only
+// depends on block b of its peers.  Same rounding points as the one-shot form.
+template <int CODE, int P, int MAXC>
+__global__ __launch_bounds__(1024) void all_reduce_norm2_kernel(
+        Peers pr, int rank, RowSource src, uint16_t* __restrict__ out, uint16_t* __restrict__ residual,
+        const uint16_t* __restrict__ gamma, int rows, int hidden, float eps) {
+    __shared__ float scratch[16];
+    Flags* mine = pr.flags[rank];
+    const uint32_t epoch = mine->epoch[blockIdx.x] + 1;
+    const int nchunk = hidden >> 3;
+    const int R = rows / P;
+    u32x4_t* ov = reinterpret_cast<u32x4_t*>(out);
+    u32x4_t* rv = reinterpret_cast<u32x4_t*>(residual);
+    u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
+    u32x4_t* res = reinterpret_cast<u32x4_t*>(pr.result[rank]);
+
+    auto poison = [&]() {
+        for (int s = 0; s < P; ++s)
+            for (int j = blockIdx.x; j < R; j += gridDim.x)
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = threadIdx.x + i * blockDim.x;
+                    if (c < nchunk) ov[(long)(s * R + j) * nchunk + c] = nan_vec<CODE>();
+                }
+        if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+    };
+
+    for (int s = 0; s < P; ++s)
+        for (int j = blockIdx.x; j < R; j += gridDim.x) {
+            const long base = (long)(s * R + j) * nchunk;
+#pragma unroll
+            for (int i = 0; i < MAXC; ++i) {
+                const int c = threadIdx.x + i * blockDim.x;
+                if (c < nchunk) st[base + c] = load_chunk<CODE>(src, base + c);
+            }
+        }
+    if (!block_barrier<P>(pr, rank, 0, epoch, true)) { poison(); return; }
+
+    const u32x4_t* wr = reinterpret_cast<const u32x4_t*>(gamma);
+    for (int j = blockIdx.x; j < R; j += gridDim.x) {
+        const long base = (long)(rank * R + j) * nchunk;
+        float v[MAXC][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + i * blockDim.x;
+            if (c < nchunk) ss += reduce_add_chunk<CODE, P>(pr, base + c, rv + (long)j * nchunk + c, v[i]);
+        }
+        ss = block_sum(ss, scratch);
+        const float rstd = rsqrtf(ss / (float)hidden + eps);
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + i * blockDim.x;
+            if (c < nchunk) {
+                float w[8], o[8];
+                unpack8<CODE>(wr[c], w);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) o[k] = v[i][k] * rstd * w[k];
+                const u32x4_t ov8 = pack8<CODE>(o);
+                res[base + c] = ov8;
+                ov[base + c] = ov8;
+            }
+        }
+    }
+    if (!block_barrier<P>(pr, rank, 1, epoch, true)) { poison(); return; }
+
+    for (int j = blockIdx.x; j < R; j += gridDim.x)
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = threadIdx.x + i * blockDim.x;
+            if (c < nchunk) {
+                u32x4_t v[P];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    v[p] = reinterpret_cast<const u32x4_t*>(pr.result[p])[(long)(p * R + j) * nchunk + c];
+#pragma unroll
+                for (int p = 0; p < P; ++p)
+                    if (p != rank) ov[(long)(p * R + j) * nchunk + c] = v[p];
+            }
+        }
+    block_barrier<P>(pr, rank, 2, epoch, false);            // peers are done reading my buffers
+    if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+}
+
 template <int CODE, int P>
-int launch_norm(const Peers& pr, int rank, void* x, void* residual, const void* gamma, int rows,
-                int hidden, float eps, hipStream_t st) {
+int launch_norm(const Peers& pr, int rank, const RowSource& src, void* out, void* residual,
+                const void* gamma, int rows, int hidden, float eps, bool two_shot, hipStream_t st) {
     const int nchunk = hidden / 8;
     int threads = 64;                                       // as elementwise.hip's launch_rms
     while (threads < nchunk && threads < 1024) threads <<= 1;
     const int per = (nchunk + threads - 1) / threads;
-    const unsigned blocks = (unsigned)(rows < kMaxBlocks ? rows : kMaxBlocks);
-    auto X = (uint16_t*)x; auto R = (uint16_t*)residual; auto G = (const uint16_t*)gamma;
-    if (per <= 1)
-        all_reduce_norm_kernel<CODE, P, 1><<<blocks, threads, 0, st>>>(pr, rank, X, R, G, rows, hidden, eps);
-    else if (per <= 2)
-        all_reduce_norm_kernel<CODE, P, 2><<<blocks, threads, 0, st>>>(pr, rank, X, R, G, rows, hidden, eps);
-    else if (per <= 4)
-        all_reduce_norm_kernel<CODE, P, 4><<<blocks, threads, 0, st>>>(pr, rank, X, R, G, rows, hidden, eps);
-    else
-        return -1;
+    const int own = two_shot ? rows / P : rows;
+    const unsigned blocks = (unsigned)(own < kMaxBlocks ? own : kMaxBlocks);
+    auto O = (uint16_t*)out; auto R = (uint16_t*)residual; auto G = (const uint16_t*)gamma;
+#define MVL_NORM(MAXC)                                                                              \
+    do {                                                                                            \
+        if (two_shot) all_reduce_norm2_kernel<CODE, P, MAXC><<<blocks, threads, 0, st>>>(           \
+                pr, rank, src, O, R, G, rows, hidden, eps);                                         \
+        else all_reduce_norm_kernel<CODE, P, MAXC><<<blocks, threads, 0, st>>>(                     \
+                pr, rank, src, O, R, G, rows, hidden, eps);                                         \
+    } while (0)
+    if (per <= 1) MVL_NORM(1);
+    else if (per <= 2) MVL_NORM(2);
+    else if (per <= 4) MVL_NORM(4);
+    else return -1;
+#undef MVL_NORM
     return MVL_CHECK_LAUNCH();
 }
 
 template <int CODE>
-int launch_norm_p(const Peers& pr, int world, int rank, void* x, void* residual, const void* gamma,
-                  int rows, int hidden, float eps, hipStream_t st) {
+int launch_norm_p(const Peers& pr, int world, int rank, const RowSource& src, void* out,
+                  void* residual, const void* gamma, int rows, int hidden, float eps, bool two_shot,
+                  hipStream_t st) {
     switch (world) {
-        case 2: return launch_norm<CODE, 2>(pr, rank, x, residual, gamma, rows, hidden, eps, st);
-        case 4: return launch_norm<CODE, 4>(pr, rank, x, residual, gamma, rows, hidden, eps, st);
-        case 8: return launch_norm<CODE, 8>(pr, rank, x, residual, gamma, rows, hidden, eps, st);
+        case 2: return launch_norm<CODE, 2>(pr, rank, src, out, residual, gamma, rows, hidden, eps, two_shot, st);
+        case 4: return launch_norm<CODE, 4>(pr, rank, src, out, residual, gamma, rows, hidden, eps, two_shot, st);
+        case 8: return launch_norm<CODE, 8>(pr, rank, src, out, residual, gamma, rows, hidden, eps, two_shot, st);
         default: return -1;
     }
 }
@@ -328,6 +470,22 @@ extern "C" int mvl_car_ipc_open(const void* handle, void** out) {
 }
 extern "C" int mvl_car_ipc_close(void* p) { return (int)hipIpcCloseMemHandle(p); }
 
+static long g_loopback = 0;
+
+// Shard rehearsal (one rank of a `world`-way group alone on its GPU): every later launch treats
+// the pointer tables as all-own and lets barrier lane p stand in for peer p.
+extern "C" void mvl_car_set_loopback(int on) { g_loopback = on; }
+
+static void fill_peers(Peers& pr, void* const* flags, void* const* stage, void* const* result, int world) {
+    for (int p = 0; p < world; ++p) {
+        pr.flags[p] = (Flags*)flags[p];
+        pr.stage[p] = (uint16_t*)stage[p];
+        pr.result[p] = result ? (uint16_t*)result[p] : nullptr;
+    }
+    pr.timeout_ticks = g_timeout_ticks;
+    pr.loopback = (int)g_loopback;
+}
+
 // flags / stage / result: `world` device pointers each, indexed by rank (own entries are the
 // local allocations, the others IPC mappings).  x: [n_elems] 16-bit elements, in place.
 extern "C" int mvl_car_all_reduce(void* const* flags, void* const* stage, void* const* result,
@@ -338,37 +496,37 @@ extern "C" int mvl_car_all_reduce(void* const* flags, void* const* stage, void* 
     const long n_vec = n_elems / 8;
     if (two_shot && n_vec % world != 0) return -1;
     Peers pr;
-    for (int p = 0; p < world; ++p) {
-        pr.flags[p] = (Flags*)flags[p];
-        pr.stage[p] = (uint16_t*)stage[p];
-        pr.result[p] = (uint16_t*)result[p];
-    }
-    pr.timeout_ticks = g_timeout_ticks;
+    fill_peers(pr, flags, stage, result, world);
     auto st = (hipStream_t)stream;
     return dtype == 0 ? launch_p<0>(pr, world, rank, x, n_vec, two_shot != 0, st)
                       : launch_p<1>(pr, world, rank, x, n_vec, two_shot != 0, st);
 }
 
-// x [rows, hidden] (contiguous, this rank's partial sums) becomes rms_norm(sum + residual) * gamma;
-// residual [rows, hidden] becomes sum + residual.  One-shot only: rows * hidden * 2 bytes must
-// fit the staging buffer (the caller checks its size).
-extern "C" int mvl_car_all_reduce_norm(void* const* flags, void* const* stage, int world, int rank,
-                                       void* x, void* residual, const void* gamma, int rows,
-                                       int hidden, float eps, int dtype, void* stream) {
+// out [rows, hidden] = rms_norm(sum over ranks + residual) * gamma, residual <- sum + residual.
+// The rank's contribution is x [rows, hidden] (contiguous; out may alias it) or, when parts is
+// given, the fp32 K-slice partials [nparts][rows][hidden] that sum to it.
+// two_shot == 0: `residual` is the full [rows, hidden] stream (replicated on every rank).
+// two_shot != 0: rows % world == 0 and `residual` is this rank's [rows / world, hidden] slice.
+// rows * hidden * 2 bytes must fit the staging (and result) buffer: the caller checks.
+extern "C" int mvl_car_all_reduce_norm(void* const* flags, void* const* stage, void* const* result,
+                                       int world, int rank, const void* x, const float* parts,
+                                       int nparts, void* out, void* residual, const void* gamma,
+                                       int rows, int hidden, float eps, int two_shot, int dtype,
+                                       void* stream) {
     if (rows == 0) return 0;
     if (world > kMaxRanks || hidden % 8 != 0 || hidden > 8 * 1024 * 4 ||
-        (((uintptr_t)x | (uintptr_t)residual | (uintptr_t)gamma) & 15) != 0)
+        (((uintptr_t)x | (uintptr_t)parts | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)gamma) & 15) != 0)
         return -1;
+    if (two_shot && (rows % world != 0 || result == nullptr)) return -1;
+    if (parts == nullptr ? x == nullptr : nparts < 1) return -1;
     Peers pr;
-    for (int p = 0; p < world; ++p) {
-        pr.flags[p] = (Flags*)flags[p];
-        pr.stage[p] = (uint16_t*)stage[p];
-        pr.result[p] = nullptr;
-    }
-    pr.timeout_ticks = g_timeout_ticks;
+    fill_peers(pr, flags, stage, result, world);
+    RowSource src;
+    src.x = (const uint16_t*)x; src.parts = parts; src.nparts = nparts; src.slab = (long)rows * hidden;
     auto st = (hipStream_t)stream;
-    return dtype == 0 ? launch_norm_p<0>(pr, world, rank, x, residual, gamma, rows, hidden, eps, st)
-                      : launch_norm_p<1>(pr, world, rank, x, residual, gamma, rows, hidden, eps, st);
+    return dtype == 0
+        ? launch_norm_p<0>(pr, world, rank, src, out, residual, gamma, rows, hidden, eps, two_shot != 0, st)
+        : launch_norm_p<1>(pr, world, rank, src, out, residual, gamma, rows, hidden, eps, two_shot != 0, st);
 }
 
 // Longest time a block waits for a peer's flag before it gives up (default 2 s).  Takes effect

@@ -58,6 +58,9 @@ class Batch:
     num_decode_seqs: int = 0
     num_prefill_tokens: int = 0
     num_prefill_k_tokens: int = 0       # sum of the context lengths of the prefill sequences
+    # decode step under tensor parallelism: rank 0 launches the step after this one ahead of
+    # this one's read-back, and every worker has to enqueue that step too
+    prelaunch: bool = False
     arrays: Dict[str, np.ndarray] = field(default_factory=dict)
 
     def scalars(self) -> dict:
@@ -67,7 +70,7 @@ class Batch:
                     step=self.step, tables_unchanged=self.tables_unchanged,
                     num_decode_seqs=self.num_decode_seqs,
                     num_prefill_tokens=self.num_prefill_tokens,
-                    num_prefill_k_tokens=self.num_prefill_k_tokens)
+                    num_prefill_k_tokens=self.num_prefill_k_tokens, prelaunch=self.prelaunch)
 
 
 _CHECK_BATCHES = os.environ.get("MINIVLLM_CHECK_BATCHES") == "1"
@@ -112,7 +115,8 @@ class ModelRunner:
         self.cfg: EngineConfig = as_engine_config(config)
         cfg = self.cfg
         self.rank = rank
-        self.world_size = cfg.world_size
+        self.world_size = cfg.world_size       # processes of this engine
+        self.tp = cfg.tp_degree                # ways the model is sharded (a shard rehearsal: > processes)
         self.block_size = cfg.block_size
         self.enforce_eager = cfg.enforce_eager
         dev_type = cfg.resolved_device()
@@ -130,9 +134,10 @@ class ModelRunner:
         self.kv_dtype = torch.float8_e4m3fn if cfg.kv_cache_dtype == "fp8" else self.dtype
 
         pg.init_tensor_parallel(rank, cfg.world_size, cfg.dist_backend, cfg.master_addr,
-                                cfg.master_port, self.device, force_group=cfg.force_tp_group)
+                                cfg.master_port, self.device, force_group=cfg.force_tp_group,
+                                shard_of=cfg.tp_shard, shard_rank=cfg.tp_shard_rank)
 
-        if (self.on_gpu and cfg.world_size > 1
+        if (self.on_gpu and self.tp > 1
                 and (cfg.custom_all_reduce or os.environ.get("MINIVLLM_CUSTOM_AR") == "1")):
             pg.enable_custom_all_reduce(self.device, one_shot_max_bytes=cfg.car_one_shot_max_bytes,
                                         timeout_ms=cfg.car_timeout_ms)
@@ -176,10 +181,8 @@ class ModelRunner:
 
         with torch.inference_mode():
             self.warmup_model()
-            if self.on_gpu and cfg.tune_decode_gemms:
-                self._tune_decode_gemms()
-            if self.on_gpu and cfg.tune_prefill_gemms:
-                self._tune_prefill_gemms()
+            if self.on_gpu and (cfg.tune_decode_gemms or cfg.tune_prefill_gemms):
+                self._choose_gemm_kernels()
             self.allocate_kv_cache()
             if self.on_gpu and not self.enforce_eager:
                 self._capture_graphs_or_fall_back()
@@ -197,6 +200,70 @@ class ModelRunner:
                 if spawn_loop:
                     self.loop()
 
+    # ------------------------------------------------------- GEMM kernel choices
+    def _gemm_choice_key(self) -> str:
+        """Everything the start-up measurements depend on."""
+        from minivllm_amd.ops import hip
+        m, cfg = self.cfg.model, self.cfg
+        return "|".join(str(v) for v in (
+            torch.cuda.get_device_name(self.device), hip.kernel_library_stamp(),
+            m.hidden_size, m.num_heads, m.num_kv_heads, m.head_dim, m.intermediate_size,
+            f"tp{self.tp}", self.dtype, f"seqs{self.max_bs}", f"tok{cfg.max_num_batched_tokens}",
+            f"dec{int(cfg.tune_decode_gemms)}", f"pre{int(cfg.tune_prefill_gemms)}",
+            f"p2p{int(pg.custom_all_reduce() is not None)}", f"coll{int(pg.collectives_active())}"))
+
+    def _gemm_choice_path(self) -> Optional[str]:
+        path = os.environ.get("MINIVLLM_GEMM_CHOICES", self.cfg.gemm_choice_cache)
+        if path == "auto":
+            path = os.path.join(os.path.expanduser("~"), ".cache", "minivllm_amd", "gemm_choices.json")
+        return path or None
+
+    def _choose_gemm_kernels(self) -> None:
+        """Hand-written kernel or library, per projection and row bucket: loaded from the choice
+        cache when this (GPU type, kernel build, model shard, limits) has been measured before,
+        measured now otherwise (and saved).  With several ranks only rank 0 does either and
+        broadcasts its table, so that every rank runs the same kernels."""
+        import json
+        from minivllm_amd.ops import hip
+        self.gemm_choice_source = "measured"
+        tables = None
+        if self.rank == 0:
+            path, key = self._gemm_choice_path(), self._gemm_choice_key()
+            store = {}
+            if path and os.path.exists(path):
+                try:
+                    with open(path) as f:
+                        store = json.load(f)
+                except (OSError, ValueError):
+                    store = {}
+            if key in store:
+                hip.import_gemm_choices(store[key])
+                self.gemm_choice_source = f"cache:{path}"
+            else:
+                hip.import_gemm_choices({})              # start from empty tables
+                if self.cfg.tune_decode_gemms:
+                    self._tune_decode_gemms()
+                if self.cfg.tune_prefill_gemms:
+                    self._tune_prefill_gemms()
+                if path:
+                    store[key] = hip.export_gemm_choices()
+                    try:
+                        os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+                        tmp = f"{path}.{os.getpid()}.tmp"
+                        with open(tmp, "w") as f:
+                            json.dump(store, f)
+                        os.replace(tmp, path)
+                    except OSError:
+                        pass                             # a read-only home: measure every time
+            tables = hip.export_gemm_choices()
+        if self.world_size > 1:
+            box = [tables]
+            torch.distributed.broadcast_object_list(box, src=0, group=pg.tp_group())
+            if self.rank != 0:
+                hip.import_gemm_choices(box[0])
+                self.gemm_choice_source = "rank 0"
+        self.gemm_choices = hip.export_gemm_choices()
+
     def _tune_decode_gemms(self) -> None:
         """Per projection and row bucket: hand-written weight-streaming kernel or library GEMM,
         decided by timing both on this model's own weights (before the decode graphs are
@@ -209,18 +276,21 @@ class ModelRunner:
                  "down": ([l.mlp.down_proj.weight for l in layers], False)}
         self.decode_gemm_choices = {}
         self.mid_gemm_choices = {}
+        # o / down feed a residual add + norm.  On one rank their K-slice sum is folded into
+        # that norm; under the peer-to-peer all-reduce into the staging pass of the fused
+        # reduce + norm kernel; with RCCL between GEMM and norm the slices are summed first.
+        sharded = self.tp > 1 or pg.collectives_active()
+        fold_slices = not sharded or pg.custom_all_reduce() is not None
         # decode batches are at most max_num_sequences rows: tune the buckets that can occur
         rows = [b for b in hip.MID_ROW_BUCKETS if b // 2 < self.max_bs]
         for name, (ws, swiglu) in roles.items():
             self.decode_gemm_choices[name] = hip.tune_skinny_gemm(ws, swiglu)
-            if name in ("o", "down") and self.world_size == 1:
+            if name in ("o", "down") and fold_slices:
                 # few column tiles: K may also be split over workgroups, the norm behind the
                 # projection sums the slices (rows: library us, kernel us, split; 0 = library)
                 self.decode_gemm_choices[name + "+norm"] = hip.tune_skinny_to_norm(ws)
             if self.max_bs > hip.SKINNY_MAX_ROWS:
-                # o / down feed a residual add + norm: on one rank their K-slice sum is folded
-                # into that norm, so they are tuned together with it
-                to_norm = name in ("o", "down") and self.world_size == 1
+                to_norm = name in ("o", "down") and fold_slices
                 self.mid_gemm_choices[name] = hip.tune_mid_gemm(ws, swiglu, rows=rows,
                                                                 to_norm=to_norm)
         torch.cuda.synchronize()
@@ -259,7 +329,7 @@ class ModelRunner:
             # scratch the decode kernel needs to exist before any graph is captured
             from minivllm_amd.ops import hip
             groups = -(-(cfg.model.num_heads // cfg.model.num_kv_heads) // 16)
-            hip.decode_ticket_words(self.device, mb * max(1, cfg.model.num_kv_heads // self.world_size)
+            hip.decode_ticket_words(self.device, mb * max(1, cfg.model.num_kv_heads // self.tp)
                                     * groups)
         # decode: fixed layout so that graphs can bake the addresses in
         self._dec_off = {}
@@ -342,8 +412,18 @@ class ModelRunner:
         while True:
             method, scalars, arrays = self.channel.recv(self.rank - 1)
             if method == "run_batch":
+                self._spec = None
+                b = Batch(arrays=arrays, **scalars)
                 with torch.inference_mode():
-                    self.execute(Batch(arrays=arrays, **scalars))
+                    if b.prelaunch:              # rank 0 runs this step and launches the next
+                        self._prelaunch_after(None, b, self._launch_decode(b))
+                    else:
+                        self.execute(b)
+            elif method == "prelaunch_next":     # rank 0 keeps launching ahead: one more step
+                with torch.inference_mode():
+                    self._prelaunch_after(None, self._spec["batch"], self._spec["tokens"])
+                if self._spec["batch"].step % self.P2P_CHECK_EVERY == 0:
+                    pg.check_custom_all_reduce(synchronize=True)
             elif method == "exit":
                 self.exit()
                 break
@@ -438,7 +518,7 @@ class ModelRunner:
     def kv_block_bytes(self) -> int:
         m = self.cfg.model
         itemsize = torch.empty((), dtype=self.kv_dtype).element_size()
-        return (2 * m.num_layers * self.block_size * (m.num_kv_heads // self.world_size)
+        return (2 * m.num_layers * self.block_size * (m.num_kv_heads // self.tp)
                 * m.head_dim * itemsize)
 
     def allocate_kv_cache(self) -> None:
@@ -470,7 +550,7 @@ class ModelRunner:
         if num_blocks <= 0:
             raise RuntimeError("not enough device memory for a single KV-cache block")
         self.num_kv_blocks = int(num_blocks)
-        hkv = m.num_kv_heads // self.world_size
+        hkv = m.num_kv_heads // self.tp
         # physical order [2, layer, block, kv_head, token, d]; layers see the logical
         # [block, token, kv_head, d] view of it
         self.kv_cache = torch.zeros(2, m.num_layers, self.num_kv_blocks, hkv, self.block_size,
@@ -611,10 +691,11 @@ class ModelRunner:
             batch = self.prepare_decode(seqs)
         self.step_counter += 1
         batch.step = self.step_counter
+        batch.prelaunch = allow_prelaunch and self._can_prelaunch(batch)
         if self.world_size > 1 and self.rank == 0:
             self.channel.send("run_batch", batch.scalars(), batch.arrays)
         with torch.inference_mode(), trace_range("prefill_step" if is_prefill else "decode_step"):
-            if allow_prelaunch and self._can_prelaunch(batch):
+            if batch.prelaunch:
                 tokens_dev = self._launch_decode(batch)
                 pending = self._read_tokens_async(tokens_dev, batch.num_seqs)
                 self._prelaunch_after(seqs, batch, tokens_dev)
@@ -634,9 +715,13 @@ class ModelRunner:
     # only then does the host wait for step n's tokens.  A sequence that turns out to have
     # finished at step n (EOS) simply has its row of step n + 1 ignored: what that row wrote
     # to the KV cache lies beyond the sequence's tokens, in a block that is not shared.
+    # Tensor-parallel engines do the same on every rank: the samples of step n are on every
+    # rank's device (each rank reduces the gathered (score, index) pairs itself), so a worker
+    # derives step n + 1 from step n exactly as rank 0 does.  Rank 0 says so in the batch it
+    # broadcasts (``Batch.prelaunch``) and sends one small "prelaunch_next" message for every
+    # further step launched ahead; the workers never read tokens back.
     def _can_prelaunch(self, b: Batch) -> bool:
-        if (b.is_prefill or not self.cfg.decode_prelaunch or self.world_size > 1
-                or pg.collectives_active() or "top_k" in b.arrays):
+        if b.is_prefill or not self.cfg.decode_prelaunch or "top_k" in b.arrays:
             return False
         if os.environ.get("MINIVLLM_NO_PRELAUNCH") == "1":
             return False
@@ -701,8 +786,7 @@ class ModelRunner:
         m = int(lens.max())
         nxt = Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1, max_seqlen_k=m,
                     max_context_len=m, arrays=arrays, tables_unchanged=True)
-        self.step_counter += 1
-        nxt.step = self.step_counter
+        nxt.step = self.step_counter = b.step + 1        # workers take the count from the batch
         out_dev = self._launch_decode(nxt, input_ids_dev=tokens_dev)
         self._spec = dict(seqs=seqs, batch=nxt, tokens=out_dev)
 
@@ -729,6 +813,8 @@ class ModelRunner:
         with torch.inference_mode(), trace_range("decode_step"):
             pending = self._read_tokens_async(spec["tokens"], b.num_seqs)
             if allow_prelaunch and len(alive) == b.num_seqs and self._can_prelaunch(b):
+                if self.world_size > 1:
+                    self.channel.send("prelaunch_next", {})
                 self._prelaunch_after(seqs, b, spec["tokens"])
             out = self._finish_read(pending)
         # a normal step for the same list continues from here (prepare_decode's shortcut)
@@ -922,7 +1008,14 @@ class ModelRunner:
             allp = pg.tp_all_gather_stack(pair)                                 # [tp, B, 2]
             best = allp[..., 0].argmax(dim=0)
             return allp[..., 1].gather(0, best[None]).squeeze(0).to(torch.int32)
-        logits = self.model.compute_logits(hidden)
+        if self.world_size > 1 or pg.is_rehearsal():
+            # CPU ranks (gloo): every rank assembles the full logits and draws the same token from
+            # its identically seeded generator, so that workers hold the step's samples as GPU
+            # ranks do (a decode step launched ahead feeds them back without rank 0's help)
+            head = self.model.lm_head
+            logits = pg.tp_all_gather(head.local_logits(hidden), dim=-1)[..., :head.num_embeddings]
+        else:
+            logits = self.model.compute_logits(hidden)
         self._last_logits = logits
         if logits is None:
             return None

@@ -195,10 +195,15 @@ class Scheduler:
         if scheduled and not deferred and not self.waiting:
             # after this step a sequence holds n + 1 tokens; the step scheduled for length m
             # is plain unless m % bs is 0 (publishes a hash) or 1 (needs a new block)
-            plain = bs
+            plain, wanted = bs, 0
             for seq in scheduled:
                 r = (seq.num_tokens + 1) % bs
                 plain = min(plain, 0 if r <= 1 else bs - r)
+                # steps after this one in which the sequence still wants a token
+                wanted = max(wanted, seq.max_tokens - seq.num_completion_tokens - 1)
+            # once every sequence has reached its max_tokens there is no next step: a step
+            # launched ahead of that point would run (and be drained) for nothing
+            plain = min(plain, wanted)
             self._decode_batch, self._plain_decode_steps = scheduled, (plain if bs > 2 else 0)
         else:
             self._decode_batch = None

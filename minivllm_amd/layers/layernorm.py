@@ -39,10 +39,7 @@ class RMSNorm(nn.Module):
 
     def forward(self, x: torch.Tensor, residual: Optional[torch.Tensor] = None
                 ) -> Union[torch.Tensor, Tuple[torch.Tensor, torch.Tensor]]:
-        if getattr(x, "_mvl_pending_reduce", False):   # row-parallel partial sum: reduce here
-            from minivllm_amd.parallel import group as pg
-            h, residual_out = pg.tp_reduce_add_rms_norm(x, residual, self.weight, self.eps)
-            return h if residual is None else (h, residual_out)
+        # ``x`` may be a projection's pending work (ops.partials): ops takes it over
         if residual is None:
             return ops.rms_norm(x, self.weight, self.eps)
         return ops.add_rms_norm(x, residual, self.weight, self.eps)

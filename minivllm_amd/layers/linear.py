@@ -152,15 +152,16 @@ class RowParallelLinear(LinearBase):
 
     def forward(self, x, defer_reduce: bool = False):
         """``defer_reduce``: the caller hands the result to ``ops.norm_linear`` / ``RMSNorm``
-        with a residual; for decode-sized outputs under the peer-to-peer all-reduce the partial
-        sum is then returned tagged (``pg.is_pending_reduce``) and that consumer reduces, adds
-        and normalises in one kernel.  On a single rank the same flag lets a K-split decode GEMM
-        hand its unsummed slices (``ops.hip.SplitKPartials``) to that consumer."""
+        with a residual and to nothing else.  Under the peer-to-peer all-reduce the partial sum
+        of a decode-sized output is then returned as ``ops.PendingReduce`` and that consumer
+        reduces, adds and normalises in one kernel.  The same flag lets a K-split decode GEMM
+        hand its unsummed slices (``ops.SplitKPartials``) on: to the norm on a single rank, to
+        the reducing kernel (which sums them while staging) otherwise."""
         bias = self.bias if self.tp_rank == 0 else None
         if (self.tp_size > 1 or pg.collectives_active()) and self.reduce_results:
             if defer_reduce and x.dim() == 2 and pg.can_defer_reduce(
                     x.shape[0], self.weight.shape[0], x.dtype, x.is_cuda):
-                return pg.mark_pending_reduce(ops.linear(x, self.weight, bias))
+                return ops.PendingReduce(ops.linear(x, self.weight, bias, to_norm=bias is None))
             from minivllm_amd.parallel.overlap import row_parallel_linear
             return row_parallel_linear(x, self.weight, bias)
         return ops.linear(x, self.weight, bias, to_norm=defer_reduce and x.dim() == 2)

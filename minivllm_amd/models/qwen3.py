@@ -118,6 +118,8 @@ class Qwen3DecoderLayer(nn.Module):
         qkv_proj, gate_up = self.self_attn.qkv_proj, self.mlp.gate_up_proj
         qkv, residual = ops.norm_linear(hidden, residual, n1.weight, n1.eps, qkv_proj.weight,
                                         qkv_proj.bias, gamma_folded=n1.folded)
+        # o and down hand their result to the norm behind them and to nothing else, so they may
+        # leave work to it (ops.PendingReduce / ops.SplitKPartials instead of a tensor)
         hidden = self.self_attn.attend(positions, qkv, defer_reduce=True)
         act, residual = ops.norm_linear(hidden, residual, n2.weight, n2.eps, gate_up.weight,
                                         gate_up.bias, swiglu=True, gamma_folded=n2.folded)
@@ -144,6 +146,9 @@ class Qwen3Model(nn.Module):
         for layer in self.layers:
             hidden, residual = layer(positions, hidden, residual)
         hidden, _ = self.norm(hidden, residual)
+        # a projection's pending work (K slices to sum, an all-reduce to run: ops.partials) is
+        # taken over by the norm behind it; none may survive the last one
+        assert torch.is_tensor(hidden), f"pending {type(hidden).__name__} left the decoder stack"
         return hidden
 
 

@@ -9,6 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from . import torch_ref
+from .partials import PendingReduce, ResidualShard, SplitKPartials
 
 
 def _hip():
@@ -21,16 +22,32 @@ def _on_gpu(t: torch.Tensor) -> bool:
 
 
 def rms_norm(x, weight, eps):
+    if isinstance(x, PendingReduce):
+        return _reduce_add_rms_norm(x, None, weight, eps)[0]
     if _is_partials(x):
         x = x.materialize()
     return _hip().rms_norm(x, weight, eps) if _on_gpu(x) else torch_ref.rms_norm(x, weight, eps)
 
 
 def _is_partials(x) -> bool:
-    return not torch.is_tensor(x) and type(x).__name__ == "SplitKPartials"
+    return isinstance(x, SplitKPartials)
+
+
+def _reduce_add_rms_norm(x: PendingReduce, residual, weight, eps):
+    from ..parallel import group as pg
+    return pg.tp_reduce_add_rms_norm(x, residual, weight, eps)
 
 
 def add_rms_norm(x, residual, weight, eps):
+    """``r = x + residual``; returns ``(rms_norm(r) * weight, r)``.  ``x`` may be a projection's
+    pending work (``PendingReduce``: all-reduce still to do; ``SplitKPartials``: K slices still
+    to sum), which the norm then takes over; ``r`` may come back as a ``ResidualShard`` (and be
+    passed in as one) when the reduce ran as the two-shot peer-to-peer kernel."""
+    if isinstance(x, PendingReduce):
+        return _reduce_add_rms_norm(x, residual, weight, eps)
+    if isinstance(residual, ResidualShard):
+        raise TypeError("a row-sharded residual stream can only be consumed together with a "
+                        "pending row-parallel reduce")
     if _is_partials(x):
         return x.add_rms_norm(residual, weight, eps)
     if _on_gpu(x):
@@ -107,7 +124,7 @@ def linear(x, weight, bias=None, to_norm=False):
     shapes where the hand-written kernels were measured to be faster on this machine.  ``to_norm``: the
     caller passes the result straight to ``norm_linear`` / ``add_rms_norm`` (and to nothing
     else), which lets a K-split mid-batch GEMM hand over its unsummed slices
-    (``hip.SplitKPartials``) for the norm kernel to sum."""
+    (``SplitKPartials``) for the norm kernel to sum."""
     if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 256:
         h = _hip()
         if x.shape[0] <= 16:
@@ -157,10 +174,12 @@ def norm_linear(x, residual, gamma, eps, weight, bias=None, swiglu=False, gamma_
     was multiplied by ``gamma`` along its input dimension at load time (``gamma`` itself is all
     ones then); only such weights can take the one-kernel path, every other case runs the norm
     kernel followed by the projection."""
-    if getattr(x, "_mvl_pending_reduce", False):       # row-parallel partial sum: reduce here
-        from ..parallel import group as pg
-        h, residual = pg.tp_reduce_add_rms_norm(x, residual, gamma, eps)
+    if isinstance(x, PendingReduce):                   # row-parallel partial sum: reduce here
+        h, residual = _reduce_add_rms_norm(x, residual, gamma, eps)
         return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), residual
+    if isinstance(residual, ResidualShard):
+        raise TypeError("a row-sharded residual stream can only be consumed together with a "
+                        "pending row-parallel reduce")
     if _is_partials(x):                                # K-split GEMM slices: summed by the norm
         h, residual = x.add_rms_norm(residual, gamma, eps)
         return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), residual

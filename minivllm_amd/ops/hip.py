@@ -14,6 +14,8 @@ from typing import Optional, Tuple
 
 import torch
 
+from .partials import SplitKPartials      # the type lives where CPU-only code can import it
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                          "_hip_kernels.so")
 _LIB_PATH = os.environ.get("MINIVLLM_HIP_LIB", _LIB_PATH)        # kernel experiments: another build
@@ -695,46 +697,34 @@ def mid_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     return out
 
 
-class SplitKPartials:
-    """The not yet summed K-slice partial products of a projection: ``ws`` [S, M, N] fp32 (+ the
-    bias still to be added).  Produced by ``mid_linear(..., defer=True)`` for a projection whose
-    output goes straight into (residual add +) RMSNorm; ``add_rms_norm`` sums the slices inside
-    the norm kernel, ``materialize`` gives the plain [M, N] tensor to any other consumer."""
+def splitk_materialize(part: SplitKPartials) -> torch.Tensor:
+    """Sum of the K-slice partials (+ bias) as a plain [M, N] tensor."""
+    S, M, N = part.ws.shape
+    out = torch.empty((M, N), dtype=part.dtype, device=part.ws.device)
+    _check(_mid_reduce(part.ws.data_ptr(), part.bias.data_ptr() if part.bias is not None
+                       else None, out.data_ptr(), N, M, N, S, _DT[part.dtype], _stream()),
+           "mid_reduce")
+    return out
 
-    __slots__ = ("ws", "bias", "dtype")
 
-    def __init__(self, ws: torch.Tensor, bias: Optional[torch.Tensor], dtype: torch.dtype):
-        self.ws, self.bias, self.dtype = ws, bias, dtype
-
-    @property
-    def shape(self):
-        return self.ws.shape[1:]
-
-    def materialize(self) -> torch.Tensor:
-        S, M, N = self.ws.shape
-        out = torch.empty((M, N), dtype=self.dtype, device=self.ws.device)
-        _check(_mid_reduce(self.ws.data_ptr(), self.bias.data_ptr() if self.bias is not None
-                           else None, out.data_ptr(), N, M, N, S, _DT[self.dtype], _stream()),
-               "mid_reduce")
-        return out
-
-    def add_rms_norm(self, residual: Optional[torch.Tensor], weight: torch.Tensor, eps: float):
-        """``(rms_norm(r) * weight, r)`` with ``r = sum of the slices (+ bias) + residual``;
-        ``residual`` is updated in place and returned as ``r``."""
-        if residual is None:
-            r = self.materialize()
-            return rms_norm(r, weight, eps), r
-        S, M, N = self.ws.shape
-        if (residual.shape != (M, N) or residual.dtype != self.dtype or residual.stride(1) != 1
-                or residual.stride(0) % 8 or residual.data_ptr() % 16 or N % 8 or N > 32768):
-            return add_rms_norm(self.materialize(), residual, weight, eps)
-        w = weight if weight.dtype == self.dtype else weight.to(self.dtype)
-        out = torch.empty((M, N), dtype=self.dtype, device=self.ws.device)
-        _check(_splitk_norm(self.ws.data_ptr(), self.bias.data_ptr() if self.bias is not None
-                            else None, residual.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, S,
-                            residual.stride(0), N, eps, _DT[self.dtype], _stream()),
-               "splitk_add_rms_norm")
-        return out, residual
+def splitk_add_rms_norm(part: SplitKPartials, residual: Optional[torch.Tensor],
+                        weight: torch.Tensor, eps: float):
+    """``(rms_norm(r) * weight, r)`` with ``r = sum of the slices (+ bias) + residual``;
+    ``residual`` is updated in place and returned as ``r``."""
+    if residual is None:
+        r = splitk_materialize(part)
+        return rms_norm(r, weight, eps), r
+    S, M, N = part.ws.shape
+    if (residual.shape != (M, N) or residual.dtype != part.dtype or residual.stride(1) != 1
+            or residual.stride(0) % 8 or residual.data_ptr() % 16 or N % 8 or N > 32768):
+        return add_rms_norm(splitk_materialize(part), residual, weight, eps)
+    w = weight if weight.dtype == part.dtype else weight.to(part.dtype)
+    out = torch.empty((M, N), dtype=part.dtype, device=part.ws.device)
+    _check(_splitk_norm(part.ws.data_ptr(), part.bias.data_ptr() if part.bias is not None
+                        else None, residual.data_ptr(), w.data_ptr(), out.data_ptr(), M, N, S,
+                        residual.stride(0), N, eps, _DT[part.dtype], _stream()),
+           "splitk_add_rms_norm")
+    return out, residual
 
 
 def _graph_time_ms(fn, x, weights, reps: int) -> float:
@@ -967,3 +957,32 @@ def big_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
                 bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
                 M, N, K, int(swiglu), _dt(x), _stream()), "big_gemm")
     return out
+
+
+# ------------------------------------------------- kernel-choice tables: export / import
+# Which kernel runs for a (row bucket, N, K, epilogue) is decided by a timing at start-up; two
+# starts (or two TP ranks) timing for themselves can disagree inside the measurement noise and
+# then round differently.  The tables are therefore values that can be saved, shipped to the
+# other ranks and loaded instead of measuring again.
+def export_gemm_choices() -> dict:
+    """The three choice tables as JSON-serialisable lists of [rows, N, K, tag, value]."""
+    def rows(table):
+        return [[k[0], k[1], k[2], k[3], list(v) if isinstance(v, tuple) else v]
+                for k, v in sorted(table.items(), key=lambda kv: tuple(map(str, kv[0])))]
+    return {"skinny": rows(_SKINNY_CHOICE), "mid": rows(_MID_CHOICE), "big": rows(_BIG_CHOICE)}
+
+
+def import_gemm_choices(tables: dict, replace: bool = True) -> None:
+    """Install tables produced by ``export_gemm_choices`` (``replace``: drop what is there)."""
+    for name, table in (("skinny", _SKINNY_CHOICE), ("mid", _MID_CHOICE), ("big", _BIG_CHOICE)):
+        if replace:
+            table.clear()
+        for m, n, k, tag, v in tables.get(name, ()):
+            table[(int(m), int(n), int(k), tag)] = tuple(v) if isinstance(v, list) else v
+
+
+def kernel_library_stamp() -> str:
+    """Identifies the built kernel library (a choice made for one build says nothing about
+    another)."""
+    st = os.stat(_LIB_PATH)
+    return f"{st.st_size}-{int(st.st_mtime)}"

@@ -12,11 +12,20 @@ maps the peers' allocations.  ``all_reduce(x)`` then launches the kernel on the 
 the call is hipGraph-capturable (pointers are fixed, the call counter lives in device memory).
 Messages that do not fit (too large, odd sizes, fp32) go to RCCL.
 
-``all_reduce_add_rms_norm`` is the one-shot form with its consumer folded in: the reference runs
-all-reduce, then a fused residual-add + RMSNorm kernel after every row-parallel projection
-(reference: src/myvllm/models/qwen3.py:191-195,216); for decode-sized batches the reducing kernel
-here owns whole rows, so it adds the residual stream and normalises the row itself and the second
-kernel disappears (two launches fewer per decoder layer).
+``all_reduce_add_rms_norm`` has the consumer folded in: the reference runs all-reduce, then a
+fused residual-add + RMSNorm kernel after every row-parallel projection (reference:
+src/myvllm/models/qwen3.py:191-195,216); the reducing kernel here owns whole rows, so it adds the
+residual stream and normalises the row itself and the second kernel disappears (two launches fewer
+per decoder layer).  Up to ``ONE_SHOT_MAX_BYTES`` every rank reduces every row (one-shot).  Above
+(a 256-row batch of Qwen3-8B is 2 MB) rank r reduces and normalises rows [r R, (r + 1) R) only and
+the ranks gather each other's normalised rows; the residual stream stays row-sharded
+(``ops.ResidualShard``) from one fused norm to the next, so it never crosses the links.  Either form
+also takes the producing GEMM's unsummed K-slice partials (``ops.SplitKPartials``) and sums them
+while staging.
+
+``loopback=True`` (shard rehearsal, one process): all "peers" are this rank's own buffers and every
+barrier lane raises the flag its peer would raise; data paths, fences and launch shapes are the real
+ones, the sums are not.
 
 Opt-in: ``EngineConfig.custom_all_reduce`` / ``MINIVLLM_CUSTOM_AR=1``.
 """
@@ -47,8 +56,9 @@ class PeerAllReduceError(RuntimeError):
 class CustomAllReduce:
     def __init__(self, group, rank: int, world_size: int, device: torch.device,
                  max_bytes: int = DEFAULT_MAX_BYTES, one_shot_max_bytes: Optional[int] = None,
-                 timeout_ms: Optional[int] = None):
+                 timeout_ms: Optional[int] = None, loopback: bool = False):
         from minivllm_amd.ops import hip
+        self.loopback = loopback
         self.one_shot_max_bytes = one_shot_max_bytes or ONE_SHOT_MAX_BYTES
         if world_size not in (2, 4, 8):
             raise ValueError("custom all-reduce supports 2, 4 or 8 ranks")
@@ -65,9 +75,12 @@ class CustomAllReduce:
         lib.mvl_car_status.argtypes = [vp]
         lib.mvl_car_all_reduce.argtypes = [ctypes.POINTER(vp)] * 3 + [
             ctypes.c_int, ctypes.c_int, vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp]
-        lib.mvl_car_all_reduce_norm.argtypes = [ctypes.POINTER(vp)] * 2 + [
-            ctypes.c_int, ctypes.c_int, vp, vp, vp, ctypes.c_int, ctypes.c_int, ctypes.c_float,
-            ctypes.c_int, vp]
+        lib.mvl_car_all_reduce_norm.argtypes = [ctypes.POINTER(vp)] * 3 + [
+            ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp, vp, ctypes.c_int,
+            ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, vp]
+        lib.mvl_car_set_loopback.argtypes = [ctypes.c_int]
+        lib.mvl_car_set_loopback.restype = None
+        lib.mvl_car_set_loopback(int(loopback))
         lib.mvl_car_set_timeout_ms.argtypes = [ctypes.c_long]
         lib.mvl_car_set_timeout_ms.restype = None
         lib.mvl_car_set_timeout_ms(int(timeout_ms or DEFAULT_TIMEOUT_MS))
@@ -97,7 +110,7 @@ class CustomAllReduce:
             for k in range(3):
                 arr = (vp * world_size)()
                 for r in range(world_size):
-                    if r == rank:
+                    if r == rank or loopback:
                         arr[r] = self._own[k]
                     else:
                         q = vp()
@@ -114,7 +127,7 @@ class CustomAllReduce:
         self.fused_norm_calls = 0
 
     def _exchange(self, obj) -> list:
-        out: List[Optional[object]] = [None] * self.world
+        out: List[Optional[object]] = [None] * (1 if self.loopback else self.world)
         dist.all_gather_object(out, obj, group=self.group)
         return out
 
@@ -153,34 +166,89 @@ class CustomAllReduce:
         self.calls += 1
         return x
 
-    def fits_norm(self, x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor) -> bool:
-        """Whether ``all_reduce_add_rms_norm`` takes these operands (one-shot sized, whole
-        contiguous rows, 16-byte aligned)."""
-        return (x.dim() == 2 and self.fits(x) and x.numel() * 2 <= self.one_shot_max_bytes
-                and x.shape[1] % 8 == 0 and x.shape[1] <= 32768
-                and residual.shape == x.shape and residual.dtype == x.dtype
-                and residual.is_contiguous() and residual.data_ptr() % 16 == 0
-                and gamma.dtype == x.dtype and gamma.is_contiguous()
-                and gamma.numel() == x.shape[1] and gamma.data_ptr() % 16 == 0)
+    def norm_mode(self, x, residual, gamma: torch.Tensor) -> Optional[str]:
+        """How ``all_reduce_add_rms_norm`` would run for these operands: ``"one"`` (one-shot, full
+        residual), ``"two"`` (two-shot, row-sharded residual) or None (not as one kernel).  ``x``
+        is this rank's [rows, hidden] partial sum or its ``SplitKPartials``; ``residual`` the full
+        [rows, hidden] stream or the ``ResidualShard`` an earlier two-shot call returned."""
+        from minivllm_amd.ops.partials import ResidualShard, SplitKPartials
+        if isinstance(x, SplitKPartials):
+            if x.bias is not None or not x.ws.is_contiguous() or x.ws.data_ptr() % 16:
+                return None
+            (rows, hidden), dtype = x.shape, x.dtype
+        else:
+            if x.dim() != 2 or not x.is_contiguous() or x.data_ptr() % 16:
+                return None
+            (rows, hidden), dtype = x.shape, x.dtype
+        nbytes = rows * hidden * 2
+        if (dtype not in (torch.bfloat16, torch.float16) or not 0 < nbytes <= self.max_bytes
+                or hidden % 8 or hidden > 32768 or gamma.dtype != dtype or not gamma.is_contiguous()
+                or gamma.numel() != hidden or gamma.data_ptr() % 16):
+            return None
+        if isinstance(residual, ResidualShard):
+            r = residual.rows
+            ok = (residual.total_rows == rows and rows % self.world == 0
+                  and tuple(r.shape) == (rows // self.world, hidden))
+            return "two" if ok and r.dtype == dtype and r.is_contiguous() and r.data_ptr() % 16 == 0 else None
+        if (tuple(residual.shape) != (rows, hidden) or residual.dtype != dtype
+                or not residual.is_contiguous() or residual.data_ptr() % 16):
+            return None
+        if nbytes <= self.one_shot_max_bytes:
+            return "one"
+        return "two" if rows % self.world == 0 else None
 
-    def all_reduce_add_rms_norm(self, x: torch.Tensor, residual: torch.Tensor,
-                                gamma: torch.Tensor, eps: float):
-        """``r = sum over ranks of x + residual``; ``residual <- r`` and ``x <- rms_norm(r) *
-        gamma``, both in place, in one kernel.  Same bits as ``all_reduce`` followed by the
-        fused add + norm kernel.  Returns ``(x, residual)``."""
+    def fits_norm(self, x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor) -> bool:
+        """Whether the ONE-SHOT fused form takes these operands."""
+        return self.norm_mode(x, residual, gamma) == "one"
+
+    def all_reduce_add_rms_norm(self, x, residual, gamma: torch.Tensor, eps: float,
+                                two_shot: bool = False):
+        """``r = sum over ranks of x + residual``; ``residual <- r``; returns ``(rms_norm(r) *
+        gamma, residual)`` from one kernel, with the bits of ``all_reduce`` followed by the fused
+        add + norm kernel.  ``x`` (tensor: overwritten with the result; ``SplitKPartials``: summed
+        while staged) and ``residual`` must satisfy ``norm_mode``.  ``two_shot``: this rank only
+        handles its rows of the residual stream; the second value is then an
+        ``ops.ResidualShard`` (a view of this rank's rows when ``residual`` came in whole)."""
+        from minivllm_amd.ops.partials import ResidualShard, SplitKPartials
+        if isinstance(x, SplitKPartials):
+            rows, hidden = x.shape
+            out = torch.empty((rows, hidden), dtype=x.dtype, device=x.ws.device)
+            xp, parts, nparts, dtype = None, x.ws.data_ptr(), x.ws.shape[0], x.dtype
+        else:
+            rows, hidden = x.shape
+            out, xp, parts, nparts, dtype = x, x.data_ptr(), None, 0, x.dtype
+        if two_shot:
+            if not isinstance(residual, ResidualShard):
+                per = rows // self.world
+                residual = ResidualShard(residual[self.rank * per:(self.rank + 1) * per], rows)
+            res_ptr = residual.rows.data_ptr()
+        else:
+            res_ptr = residual.data_ptr()
         rc = self._lib.mvl_car_all_reduce_norm(
-            self._flags, self._stage, self.world, self.rank, x.data_ptr(), residual.data_ptr(),
-            gamma.data_ptr(), x.shape[0], x.shape[1], float(eps),
-            0 if x.dtype == torch.bfloat16 else 1, torch.cuda.current_stream().cuda_stream)
+            self._flags, self._stage, self._result, self.world, self.rank, xp, parts, nparts,
+            out.data_ptr(), res_ptr, gamma.data_ptr(), rows, hidden, float(eps), int(two_shot),
+            0 if dtype == torch.bfloat16 else 1, torch.cuda.current_stream().cuda_stream)
         self._ck(rc, "launch")
         self.calls += 1
         self.fused_norm_calls += 1
-        return x, residual
+        return out, residual
 
     def self_test(self) -> bool:
         """All-reduce known integer patterns through both data paths and compare with the exact
         sums (collective call; the result is this rank's own verdict)."""
         P, ok = self.world, True
+        if self.loopback:
+            # every "peer" is this rank: a one-shot sum is P times the input; the two-shot and
+            # fused forms only have to complete (their barriers are what is being rehearsed)
+            x = (torch.arange(8 * P * 16, device=self.device) % 7).to(torch.bfloat16)
+            want = x.float() * P
+            ok = bool((self.all_reduce(x.clone()).float() == want).all())
+            big = torch.ones(self.one_shot_max_bytes // 2 + 8 * P * 64, device=self.device,
+                             dtype=torch.bfloat16)
+            big = big[:big.numel() - big.numel() % (8 * P)]
+            if big.numel() * 2 <= self.max_bytes:
+                self.all_reduce(big)
+            return ok and self.healthy()
         for n in (8 * P * 16, (self.one_shot_max_bytes // 2 + 8 * P * 64)):
             n -= n % (8 * P)
             if n * 2 > self.max_bytes:
@@ -203,6 +271,17 @@ class CustomAllReduce:
         h1, r1 = hip.add_rms_norm(x1, r1, gamma, 1e-6)
         h2, r2 = self.all_reduce_add_rms_norm(x2, r2, gamma, 1e-6)
         ok = ok and bool(torch.equal(h1, h2)) and bool(torch.equal(r1, r2))
+        # ... and the two-shot form (this rank's rows of the residual only) against the same route
+        rows = 2 * P
+        base = torch.randn(rows, 1024, device=self.device, dtype=torch.bfloat16, generator=g)
+        res0 = torch.randn(rows, 1024, device=self.device, dtype=torch.bfloat16, generator=g)
+        x1, r1 = base * (self.rank + 1), res0.clone()
+        x2, r2 = x1.clone(), res0.clone()
+        self.all_reduce(x1)
+        h1, r1 = hip.add_rms_norm(x1, r1, gamma, 1e-6)
+        h2, shard = self.all_reduce_add_rms_norm(x2, r2, gamma, 1e-6, two_shot=True)
+        mine = slice(self.rank * 2, self.rank * 2 + 2)
+        ok = ok and bool(torch.equal(h1, h2)) and bool(torch.equal(r1[mine], shard.rows))
         return ok and self.healthy()
 
     def healthy(self, synchronize: bool = True) -> bool:
@@ -231,4 +310,6 @@ class CustomAllReduce:
             dist.barrier(group=self.group)
         except Exception:
             pass
+        if self.loopback:
+            self._lib.mvl_car_set_loopback(0)
         self._release()

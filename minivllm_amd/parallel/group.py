@@ -20,6 +20,12 @@ import torch.distributed as dist
 _TP_RANK = 0
 _TP_SIZE = 1
 _TP_GROUP: Optional[dist.ProcessGroup] = None
+# Shard rehearsal: this process holds rank ``_TP_RANK``'s shard of a ``_TP_SIZE``-way sharded model
+# but its process group has ONE member.  Every collective of the sharded code path is issued (RCCL
+# nodes inside the decode graphs included) with nobody at the other end, so what a step costs is
+# one rank's compute, launches and collective entry/exit: the floor under that rank's step time
+# on a real node.  Outputs are not the model's (partial sums are never completed).
+_REHEARSAL = False
 _OWNS_DEFAULT_GROUP = False
 # gloo has no device transport: with GPU tensors (several ranks sharing one device, used only to
 # rehearse the TP control flow on a single-GPU machine) every collective is staged through host
@@ -56,15 +62,28 @@ def host_staged_collectives() -> bool:
     return _HOST_STAGED
 
 
+def is_rehearsal() -> bool:
+    """True when one process stands in for a rank of a larger tensor-parallel group."""
+    return _REHEARSAL
+
+
 def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
                          master_addr: str = "127.0.0.1", master_port: int = 29512,
                          device: Optional[torch.device] = None,
-                         timeout_s: float = 600.0, force_group: bool = False) -> None:
+                         timeout_s: float = 600.0, force_group: bool = False,
+                         shard_of: int = 0, shard_rank: int = 0) -> None:
     """Join the TP group.  Reuses an already initialised default group (torchrun).
     ``force_group`` creates the group even for one rank, so that every collective of the
-    sharded code path really runs (and is captured into the decode graphs) on a single GPU."""
-    global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP, _HOST_STAGED
+    sharded code path really runs (and is captured into the decode graphs) on a single GPU.
+    ``shard_of`` = N (one process only): layers are built as rank ``shard_rank`` of an N-way
+    sharded model while the process group has this one member (shard rehearsal)."""
+    global _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP, _HOST_STAGED, _REHEARSAL
     _TP_RANK, _TP_SIZE = rank, world_size
+    _REHEARSAL = False
+    if shard_of > 1:
+        if world_size != 1:
+            raise ValueError("a shard rehearsal runs in one process (world_size 1)")
+        force_group = True
     if world_size == 1 and not force_group:
         _TP_GROUP = None
         return
@@ -88,6 +107,8 @@ def init_tensor_parallel(rank: int, world_size: int, backend: str = "auto",
         assert dist.get_world_size() == world_size and dist.get_rank() == rank
     _TP_GROUP = dist.group.WORLD
     _HOST_STAGED = on_gpu and dist.get_backend(_TP_GROUP) == "gloo"
+    if shard_of > 1:
+        _TP_RANK, _TP_SIZE, _REHEARSAL = shard_rank, shard_of, True
 
 
 def enable_custom_all_reduce(device, max_bytes: Optional[int] = None,
@@ -103,8 +124,9 @@ def enable_custom_all_reduce(device, max_bytes: Optional[int] = None,
     try:
         # the constructor fails on every rank or on none (it exchanges its own status)
         car = CustomAllReduce(_TP_GROUP, _TP_RANK, _TP_SIZE, torch.device(device),
-                              max_bytes or DEFAULT_MAX_BYTES, one_shot_max_bytes, timeout_ms)
-        verdicts = [None] * _TP_SIZE
+                              max_bytes or DEFAULT_MAX_BYTES, one_shot_max_bytes, timeout_ms,
+                              loopback=_REHEARSAL)
+        verdicts = [None] * (1 if _REHEARSAL else _TP_SIZE)
         dist.all_gather_object(verdicts, car.self_test(), group=_TP_GROUP)
         if not all(verdicts):                  # wrong sums or a timed-out barrier on some rank
             car.close()
@@ -151,8 +173,9 @@ def destroy_tensor_parallel(peers_dead: bool = False) -> None:
             and not peers_dead):
         dist.destroy_process_group()
     _TP_RANK, _TP_SIZE, _TP_GROUP, _OWNS_DEFAULT_GROUP = 0, 1, None, False
-    global _HOST_STAGED
+    global _HOST_STAGED, _REHEARSAL
     _HOST_STAGED = False
+    _REHEARSAL = False
 
 
 # ------------------------------------------------------------- collectives
@@ -171,47 +194,48 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def mark_pending_reduce(x: torch.Tensor) -> torch.Tensor:
-    """Tag a row-parallel partial sum whose all-reduce is left to its consumer
-    (``tp_reduce_add_rms_norm``)."""
-    x._mvl_pending_reduce = True
-    return x
-
-
-def is_pending_reduce(x: torch.Tensor) -> bool:
-    return getattr(x, "_mvl_pending_reduce", False)
-
-
 def can_defer_reduce(rows: int, hidden: int, dtype: torch.dtype, on_gpu: bool) -> bool:
-    """True when the all-reduce of a [rows, hidden] row-parallel partial sum can be folded into
-    the (residual add + RMSNorm) that consumes it: the peer-to-peer kernel is active and the
-    tensor is one-shot sized.  The operands themselves are checked again at the consumer."""
+    """True when the all-reduce of a [rows, hidden] row-parallel partial sum may be left to the
+    (residual add + RMSNorm) that consumes it: the peer-to-peer kernel is active and the message
+    fits its buffers.  Whether that consumer really runs one fused kernel (one-shot up to a few
+    hundred KB, two-shot with a row-sharded residual above, neither for odd shapes) is decided
+    there, on the operands; every case ends in the same values."""
     if _CUSTOM_AR is None or not on_gpu or dtype not in (torch.bfloat16, torch.float16):
         return False
-    from .custom_allreduce import ONE_SHOT_MAX_BYTES
     n = rows * hidden
-    return 0 < n * 2 <= ONE_SHOT_MAX_BYTES and n % (8 * _TP_SIZE) == 0 and hidden % 8 == 0
+    return 0 < n * 2 <= _CUSTOM_AR.max_bytes and hidden % 8 == 0
 
 
-def tp_reduce_add_rms_norm(x: torch.Tensor, residual: torch.Tensor, gamma: torch.Tensor,
-                           eps: float):
-    """Consumer of a pending partial sum: ``(rms_norm(all_reduce(x) + residual) * gamma,
+def tp_reduce_add_rms_norm(x, residual, gamma: torch.Tensor, eps: float):
+    """Consumer of a ``PendingReduce``: ``(rms_norm(all_reduce(x) + residual) * gamma,
     all_reduce(x) + residual)``, as one peer-to-peer kernel when the operands allow it and as
-    all-reduce + fused add/norm otherwise."""
-    x._mvl_pending_reduce = False
-    if residual is not None and _CUSTOM_AR is not None and _CUSTOM_AR.fits_norm(x, residual, gamma):
-        return _CUSTOM_AR.all_reduce_add_rms_norm(x, residual, gamma, eps)
+    all-reduce + fused add/norm otherwise.  The second value is a ``ResidualShard`` when the
+    two-shot fused kernel ran (and ``residual`` may be one from an earlier such call)."""
     from .. import ops
-    x = tp_all_reduce(x)
+    from ..ops.partials import PendingReduce, ResidualShard, SplitKPartials
+    assert isinstance(x, PendingReduce)
+    val = x.value
+    if residual is not None and _CUSTOM_AR is not None:
+        mode = _CUSTOM_AR.norm_mode(val, residual, gamma)
+        if mode is not None:
+            return _CUSTOM_AR.all_reduce_add_rms_norm(val, residual, gamma, eps, two_shot=mode == "two")
+    if isinstance(residual, ResidualShard):
+        raise RuntimeError("the residual stream is row-sharded but this reduce cannot run as the "
+                           "two-shot fused kernel (shape or alignment changed within a step)")
+    t = val.materialize() if isinstance(val, SplitKPartials) else val
+    t = tp_all_reduce(t)
     if residual is None:
-        return ops.rms_norm(x, gamma, eps), x
-    return ops.add_rms_norm(x, residual, gamma, eps)
+        return ops.rms_norm(t, gamma, eps), t
+    return ops.add_rms_norm(t, residual, gamma, eps)
 
 
 def _all_gather_parts(x: torch.Tensor) -> List[torch.Tensor]:
     src = x.cpu() if (_HOST_STAGED and x.is_cuda) else x.contiguous()
-    parts: List[torch.Tensor] = [torch.empty_like(src) for _ in range(_TP_SIZE)]
+    n = 1 if _REHEARSAL else _TP_SIZE
+    parts: List[torch.Tensor] = [torch.empty_like(src) for _ in range(n)]
     dist.all_gather(parts, src, group=_TP_GROUP)
+    if _REHEARSAL:                    # the absent peers' shards: copies of this rank's
+        parts = parts + [parts[0].clone() for _ in range(_TP_SIZE - 1)]
     return [p.to(x.device) for p in parts] if src.device != x.device else parts
 
 
@@ -228,7 +252,11 @@ def tp_all_gather_stack(x: torch.Tensor) -> torch.Tensor:
     if not _HOST_STAGED and x.is_cuda:
         # one output buffer, one collective, no per-rank copies (graph-capture friendly)
         out = torch.empty((_TP_SIZE,) + tuple(x.shape), dtype=x.dtype, device=x.device)
-        dist.all_gather_into_tensor(out, x.contiguous(), group=_TP_GROUP)
+        if _REHEARSAL:                # one member: its slice arrives, the others are copies
+            dist.all_gather_into_tensor(out[:1], x.contiguous(), group=_TP_GROUP)
+            out[1:].copy_(out[:1].expand_as(out[1:]))
+        else:
+            dist.all_gather_into_tensor(out, x.contiguous(), group=_TP_GROUP)
         return out
     return torch.stack(_all_gather_parts(x))
 
@@ -239,6 +267,8 @@ def tp_gather(x: torch.Tensor, dst: int = 0, dim: int = -1) -> Optional[torch.Te
     if _TP_GROUP is None:
         return x
     src = x.cpu() if (_HOST_STAGED and x.is_cuda) else x.contiguous()
+    if _REHEARSAL:
+        return torch.cat(_all_gather_parts(x), dim=dim) if _TP_RANK == dst else None
     parts = [torch.empty_like(src) for _ in range(_TP_SIZE)] if _TP_RANK == dst else None
     dist.gather(src, parts, dst=dst, group=_TP_GROUP)
     return torch.cat(parts, dim=dim).to(x.device) if parts is not None else None

@@ -59,19 +59,60 @@ def _worker(rank, world, port, q):
                 h32 = r32 * torch.rsqrt(r32.pow(2).mean(-1, keepdim=True) + 1e-6) * gamma.float()
                 fused_err = max(fused_err, float((h2.float() - h32).abs().max()),
                                 float((r2.float() - r32).abs().max() / 4))
-        assert not car.fits_norm(torch.zeros(64, 4096, device="cuda", dtype=torch.bfloat16),
-                                 torch.zeros(64, 4096, device="cuda", dtype=torch.bfloat16),
-                                 torch.ones(4096, device="cuda", dtype=torch.bfloat16))
+        big = torch.zeros(64, 4096, device="cuda", dtype=torch.bfloat16)
+        assert not car.fits_norm(big, big.clone(), torch.ones(4096, device="cuda", dtype=torch.bfloat16))
+        assert car.norm_mode(big, big.clone(), torch.ones(4096, device="cuda", dtype=torch.bfloat16)) == "two"
         assert fused_exact, "fused all-reduce + norm differs from all-reduce then norm"
         assert fused_err < 0.08, fused_err
+        # two-shot fused form: rank r reduces + normalises rows [r R, (r + 1) R) only, keeps its
+        # slice of the residual stream (ResidualShard) and gathers the peers' normalised rows.
+        # Two norms in a row, as in a decoder layer (the second consumes the shard of the first);
+        # the K-slice partials of a split GEMM as input; against the two-kernel route (same bits).
+        from minivllm_amd.ops.partials import ResidualShard, SplitKPartials
+        two_exact = True
+        for dtype in (torch.bfloat16, torch.float16):
+            for rows, hidden in ((8 * world, 4096), (256, 4096), (16 * world, 5120), (world, 64),
+                                 (40 * world, 1024)):
+                R = rows // world
+                mine = slice(rank * R, (rank + 1) * R)
+                gs = torch.Generator(device="cuda").manual_seed(5 * rows + hidden)
+                res = torch.randn(rows, hidden, device="cuda", dtype=dtype, generator=gs)
+                gamma = (torch.rand(hidden, device="cuda", generator=gs) + 0.5).to(dtype)
+                r_ref, shard = res.clone(), res.clone()
+                for layer in range(2):
+                    g = torch.Generator(device="cuda").manual_seed(31 * rank + rows + hidden + layer)
+                    x = torch.randn(rows, hidden, device="cuda", dtype=dtype, generator=g)
+                    assert car.norm_mode(x, shard, gamma) == "two" or rows * hidden * 2 <= car.one_shot_max_bytes
+                    x1 = x.clone()
+                    car.all_reduce(x1)
+                    h1, r_ref = hip.add_rms_norm(x1, r_ref, gamma, 1e-6)
+                    h2, shard = car.all_reduce_add_rms_norm(x.clone(), shard, gamma, 1e-6, two_shot=True)
+                    assert isinstance(shard, ResidualShard) and tuple(shard.rows.shape) == (R, hidden)
+                    two_exact &= bool(torch.equal(h1, h2)) and bool(torch.equal(r_ref[mine], shard.rows))
+                # K-slice partials: three fp32 slices that sum to this rank's contribution
+                g = torch.Generator(device="cuda").manual_seed(17 * rank + rows)
+                ws = torch.randn(3, rows, hidden, device="cuda", dtype=torch.float32, generator=g)
+                part = SplitKPartials(ws, None, dtype)
+                x1 = part.materialize()
+                car.all_reduce(x1)
+                h1, r1 = hip.add_rms_norm(x1, res.clone(), gamma, 1e-6)
+                mode = car.norm_mode(part, res, gamma)
+                assert mode in ("one", "two")
+                h2, r2 = car.all_reduce_add_rms_norm(part, res.clone(), gamma, 1e-6, two_shot=mode == "two")
+                r2 = r2.rows if isinstance(r2, ResidualShard) else r2[mine]
+                two_exact &= bool(torch.equal(h1, h2)) and bool(torch.equal(r1[mine], r2))
+        assert two_exact, "two-shot fused all-reduce + norm differs from all-reduce then norm"
         # graph replay: three calls of different sizes in one graph, replayed on fresh inputs
         bufs = [torch.zeros(n, device="cuda", dtype=torch.bfloat16) for n in (4096, 256 * 4096, 64)]
         fx = torch.zeros(8, 256, device="cuda", dtype=torch.bfloat16)
         fr = torch.zeros(8, 256, device="cuda", dtype=torch.bfloat16)
         ones = torch.ones(256, device="cuda", dtype=torch.bfloat16)
+        tx = torch.zeros(2 * world, 256, device="cuda", dtype=torch.bfloat16)
+        tr = torch.zeros(2 * world, 256, device="cuda", dtype=torch.bfloat16)
         for b in bufs:
             car.all_reduce(b)                                # warm-up outside capture
         car.all_reduce_add_rms_norm(fx, fr, ones, 1e-6)
+        car.all_reduce_add_rms_norm(tx, tr, ones, 1e-6, two_shot=True)
         torch.cuda.synchronize()
         dist.barrier()
         g = torch.cuda.CUDAGraph()
@@ -79,12 +120,15 @@ def _worker(rank, world, port, q):
             for b in bufs:
                 car.all_reduce(b)
             car.all_reduce_add_rms_norm(fx, fr, ones, 1e-6)
+            car.all_reduce_add_rms_norm(tx, tr, ones, 1e-6, two_shot=True)
         graph_ok = True
         for it in range(3):
             for b in bufs:
                 b.fill_(float(rank + 1 + it))
             fx.fill_(float(rank + 1 + it))
             fr.fill_(1.0)
+            tx.fill_(float(rank + 1 + it))
+            tr.fill_(1.0)
             torch.cuda.synchronize()
             dist.barrier()
             g.replay()
@@ -94,6 +138,9 @@ def _worker(rank, world, port, q):
             # constant rows: the residual becomes sum + 1 and the normalised row is all ones
             graph_ok &= bool((fr.float() == expect + 1.0).all())
             graph_ok &= bool((fx.float() - 1.0).abs().max() < 1e-2)
+            # two-shot: only this rank's rows of the residual are updated; every row is normalised
+            graph_ok &= bool((tr[2 * rank:2 * rank + 2].float() == expect + 1.0).all())
+            graph_ok &= bool((tx.float() - 1.0).abs().max() < 1e-2)
             dist.barrier()
         healthy = car.healthy()
         assert not car.fits(torch.zeros(24, device="cuda", dtype=torch.float32))
@@ -187,3 +234,46 @@ def test_a_peer_that_never_arrives_poisons_the_output_and_raises():
         assert r[3] is None, r[3]
         assert r[1]
     assert res[0][2] == (True, True, True, True)
+
+
+def test_loopback_rehearsal_of_one_rank():
+    """One process standing in for a rank of an 8-way group: every barrier lane raises the flag
+    its peer would raise, all pointer tables are this rank's own buffers.  All four kernel forms
+    must complete (eagerly and as graph replays) and stay healthy; a one-shot sum over 8 copies
+    of the same buffer is 8 x the input."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import torch.distributed as dist
+    from minivllm_amd.ops.partials import ResidualShard
+    from minivllm_amd.parallel.custom_allreduce import CustomAllReduce
+    torch.cuda.set_device(0)
+    port = 29333 + os.getpid() % 200
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        car = CustomAllReduce(dist.group.WORLD, 3, 8, torch.device("cuda", 0), max_bytes=4 << 20,
+                              loopback=True)
+        assert car.self_test()
+        x = torch.full((4096,), 1.5, device="cuda", dtype=torch.bfloat16)
+        assert bool((car.all_reduce(x).float() == 12.0).all())
+        big = torch.ones(256 * 4096, device="cuda", dtype=torch.bfloat16)
+        h = torch.ones(256, 4096, device="cuda", dtype=torch.bfloat16)
+        r = torch.ones(256, 4096, device="cuda", dtype=torch.bfloat16)
+        gamma = torch.ones(4096, device="cuda", dtype=torch.bfloat16)
+        small = torch.ones(16, 4096, device="cuda", dtype=torch.bfloat16)
+        car.all_reduce(big)
+        car.all_reduce_add_rms_norm(small, small.clone(), gamma, 1e-6)
+        _, shard = car.all_reduce_add_rms_norm(h, r, gamma, 1e-6, two_shot=True)
+        assert isinstance(shard, ResidualShard) and tuple(shard.rows.shape) == (32, 4096)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
+            for _ in range(4):
+                car.all_reduce(big)
+                _, shard = car.all_reduce_add_rms_norm(h, shard, gamma, 1e-6, two_shot=True)
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        assert car.healthy() and bool(torch.isfinite(h.float()).all())
+        car.close()
+    finally:
+        dist.destroy_process_group()

@@ -492,3 +492,48 @@ def test_no_launched_ahead_step_survives_generate(gpu):
     eng.generate(prompts, SamplingParams(temperature=0.0, max_tokens=6, ignore_eos=True))
     assert eng.is_finished() and not eng.model_runner.has_prelaunched()
     eng.exit()
+
+
+@pytest.mark.parametrize("p2p", [False, True])
+def test_tp_shard_rehearsal_runs_the_sharded_step_with_graphs(gpu, p2p):
+    """``tp_shard=8``: rank 0's shard of an 8-way engine on the one GPU (4 query heads and one KV
+    head per rank, the head geometry of Qwen3-8B at TP=8), every collective issued through a
+    single-member RCCL group or (``p2p``) the peer-to-peer kernels in loop-back form - which then
+    run the fused reduce + add + norm, one-shot for small decode buckets and two-shot with a
+    row-sharded residual stream for the 64-row bucket - all inside captured decode graphs and with
+    decode steps launched ahead.  Tokens are meaningless in a rehearsal; the step must run, stay
+    finite and leave the all-reduce kernels healthy."""
+    import os
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    from minivllm_amd.parallel import group as pg
+    model = model_preset("qwen3-tiny", vocab_size=4096, num_layers=3, head_dim=128, hidden_size=1024,
+                         num_heads=32, num_kv_heads=8, intermediate_size=2048, max_position=2048)
+    eng = LLMEngine(_cfg(model=model, tp_shard=8, enforce_eager=False, graph_batch_sizes=[8, 64],
+                         max_num_sequences=64, custom_all_reduce=p2p, block_size=256,
+                         max_cached_blocks=160, master_port=29700 + os.getpid() % 100 + int(p2p),
+                         gemm_choice_cache=""))
+    try:
+        r = eng.model_runner
+        assert pg.is_rehearsal() and pg.tp_size() == 8 and (pg.custom_all_reduce() is not None) == p2p
+        layer = r.model.model.layers[0]
+        assert tuple(layer.self_attn.qkv_proj.weight.shape) == (6 * 128, 1024)
+        assert tuple(layer.mlp.down_proj.weight.shape) == (1024, 256)
+        assert r.kv_cache.shape[3] == 1 and set(r.graphs) == {8, 64}
+        sp = SamplingParams(temperature=0.8, max_tokens=24, ignore_eos=True)
+        launched = 0
+        for p in _prompts(64, lo=20, hi=300, vocab=4096, seed=21):
+            eng.add_prompt(p, sp)
+        done = {}
+        while not eng.is_finished():
+            finished, _, _ = eng.step()
+            done.update(finished)
+            launched += r.has_prelaunched()
+        assert len(done) == 64 and all(len(t) == 24 for t in done.values())
+        assert launched >= 10, launched                    # launch-ahead under collectives
+        assert bool(torch.isfinite(r._graph_logits[64].float()).all())
+        if p2p:
+            car = pg.custom_all_reduce()
+            assert car.fused_norm_calls > 0 and car.healthy()
+    finally:
+        eng.exit()
+    assert not pg.is_rehearsal()

@@ -1038,3 +1038,77 @@ def test_paged_prefill_over_fp8_cache(hip, dtype, bs, hq, hkv, d):
     got = hip.paged_attention_prefill(q, kc8, vc8, cq, ck, tables, scale, max_seqlen_q=300,
                                       max_seqlen_k=513)            # the engine's call: no sync
     close(got, want, dtype)
+
+
+# ------------------------------------- head geometries of the reference's model-shape sweep
+# qwen3-30b 40 / 8 (group of 5), llama3-70b 64 / 8 (8), qwen3-235b-moe 64 / 4 (16) (reference:
+# benchmark_models.py:10-43), plus what one rank of such a model sees under tensor parallelism
+# (5 / 1, 16 / 1) and a group wider than one 16-head pass of the decode kernel (20 / 1).
+_SWEEP_GEOMETRIES = [(40, 8), (64, 8), (64, 4), (5, 1), (16, 1), (20, 1)]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv", _SWEEP_GEOMETRIES)
+@pytest.mark.parametrize("bs", [16, 256])
+def test_paged_decode_sweep_geometries(hip, dtype, hq, hkv, bs):
+    """Decode with every split count (incl. the in-kernel split merge and the automatic choice)
+    over bf16/fp16 and fp8 caches."""
+    torch.manual_seed(90 + hq)
+    d = 128
+    lens = [1, 33, 260, 1000, 77, 512]
+    k = torch.randn(sum(lens), hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(sum(lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(k, v, lens, bs, hkv, d, dtype)
+    q = torch.randn(len(lens), hq, d, device=DEV, dtype=dtype)
+    ctx = torch.tensor(lens, device=DEV, dtype=torch.int32)
+    scale = 1.0 / math.sqrt(d)
+    want = ref.paged_attention_decode(q, kc, vc, tables, ctx, scale)
+    for ns in (1, 3, 8, 32):
+        close(hip.paged_attention_decode(q, kc, vc, tables, ctx, scale, num_splits=ns), want, dtype)
+    close(hip.paged_attention_decode(q, kc, vc, tables, ctx, scale, max_context_len=max(lens)), want, dtype)
+    kc8, vc8 = kc.to(FP8), vc.to(FP8)
+    want8 = ref.paged_attention_decode(q, kc8.to(dtype), vc8.to(dtype), tables, ctx, scale)
+    for ns in (1, 4):
+        close(hip.paged_attention_decode(q, kc8, vc8, tables, ctx, scale, num_splits=ns), want8, dtype)
+    tickets = hip.decode_ticket_words(q.device, 1)
+    torch.cuda.synchronize()
+    assert int(tickets.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv", _SWEEP_GEOMETRIES)
+def test_prefill_sweep_geometries(hip, dtype, hq, hkv):
+    """Packed prefill, paged prefill behind cached prefixes (16- and 256-token blocks), the
+    fused raw-Q transform and the fp8-cache arm."""
+    torch.manual_seed(190 + hq)
+    d = 128
+    q_lens = [1, 60, 129, 300, 64]
+    prefix = [0, 256, 0, 512, 256]
+    k_lens = [a + b for a, b in zip(q_lens, prefix)]
+    T, scale, eps = sum(q_lens), 1.0 / math.sqrt(d), 1e-6
+    cu = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    ck = torch.tensor([0] + list(torch.tensor(k_lens).cumsum(0)), device=DEV, dtype=torch.int32)
+    qkv = torch.randn(T, (hq + 2 * hkv) * d, device=DEV, dtype=dtype)
+    pos = torch.cat([torch.arange(p, p + n) for p, n in zip(prefix, q_lens)]).to(DEV, torch.int32)
+    cs = ref.build_cos_sin_cache(d, 1024, 10000.0, DEV)
+    qw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype)
+    kw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype)
+    rope = (pos, cs, qw, eps)
+    a = qkv.clone()
+    q_a, k_a, v_a = hip.qk_norm_rope_store(a, pos, cs, qw, kw, eps, hq, hkv, d, None, None, None)
+    b = qkv.clone()
+    q_b, k_b, v_b = hip.qk_norm_rope_store(b, pos, cs, qw, kw, eps, hq, hkv, d, None, None, None,
+                                           skip_q=True)
+    want = ref.flash_attention_prefill(q_a, k_a, v_a, cu, scale)
+    close(hip.flash_attention_prefill(q_a, k_a, v_a, cu, scale), want, dtype)
+    close(hip.flash_attention_prefill(q_b, k_b, v_b, cu, scale, q_rope=rope), want, dtype)
+    kk = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    vv = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    for bs in (16, 256):
+        kc, vc, tables = _fill_paged(kk, vv, k_lens, bs, hkv, d, dtype)
+        want = ref.paged_attention_prefill(q_a, kc, vc, cu, ck, tables, scale)
+        close(hip.paged_attention_prefill(q_a, kc, vc, cu, ck, tables, scale), want, dtype)
+        close(hip.paged_attention_prefill(q_b, kc, vc, cu, ck, tables, scale, q_rope=rope), want, dtype)
+        kc8, vc8 = kc.to(FP8), vc.to(FP8)
+        want8 = ref.paged_attention_prefill(q_a, kc8.to(dtype), vc8.to(dtype), cu, ck, tables, scale)
+        close(hip.paged_attention_prefill(q_a, kc8, vc8, cu, ck, tables, scale), want8, dtype)

@@ -321,3 +321,68 @@ def test_a_dead_worker_is_reported_and_teardown_does_not_stall():
     assert proc.returncode not in (0, None)
     # generous bound for a loaded CI machine; the stall this guards against was 15 minutes
     assert time.monotonic() - t0 < 45, out[-2000:]
+
+
+def _stepwise(world, port, ahead, lens=(12, 30, 7, 30)):
+    """Drive the engine step by step; returns (tokens per request, decode steps launched ahead)."""
+    import dataclasses
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    eng = LLMEngine(dataclasses.replace(_cfg(world, port), decode_prelaunch=ahead, block_size=16,
+                                        max_cached_blocks=32))
+    rng = np.random.default_rng(5)
+    seqs = [eng.add_prompt(rng.integers(0, 331, size=n).tolist(),
+                           SamplingParams(temperature=0.7 if i % 2 else 0, max_tokens=m, ignore_eos=True))
+            for i, (n, m) in enumerate(zip((5, 21, 9, 16), lens))]
+    done, launched, steps = {}, 0, 0
+    while not eng.is_finished():
+        finished, _, _ = eng.step()
+        done.update(finished)
+        launched += eng.model_runner.has_prelaunched()
+        steps += 1
+        assert steps < 300
+    eng.exit()
+    return [done[s.seq_id] for s in seqs], launched
+
+
+def test_tp2_launch_ahead_decode_matches_plain_loop():
+    """Tensor-parallel engines launch decode step n + 1 before reading step n's tokens too: the
+    workers derive it from step n on their own (``Batch.prelaunch`` / "prelaunch_next").  Same
+    tokens as the plain loop and as one rank, with sampled (temperature > 0) rows in the batch,
+    sequences that finish at different steps and KV-block edges in between."""
+    port = 29150 + os.getpid() % 250
+    plain, n0 = _stepwise(2, port, ahead=False)
+    ahead, n1 = _stepwise(2, port + 1, ahead=True)
+    single, _ = _stepwise(1, port + 2, ahead=True)
+    assert n0 == 0 and n1 >= 8, (n0, n1)
+    assert ahead == plain == single
+
+
+def test_shard_rehearsal_builds_one_ranks_shapes_and_runs():
+    """``tp_shard=N``: one process holds rank r's shard of an N-way engine (per-rank weight
+    shapes and KV heads) and issues every collective through a single-member group.  Tokens
+    are meaningless; shapes, the collective call sites and the engine loop are what is checked."""
+    import dataclasses
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    from minivllm_amd.parallel import group as pg
+    port = 29420 + os.getpid() % 250
+    base = _cfg(1, port)
+    cfg = dataclasses.replace(base, tp_shard=2, tp_shard_rank=1,
+                              model=dataclasses.replace(base.model, num_kv_heads=2))
+    eng = LLMEngine(cfg)
+    try:
+        r = eng.model_runner
+        assert pg.is_rehearsal() and pg.tp_size() == 2 and pg.tp_rank() == 1
+        layer = r.model.model.layers[0]
+        assert tuple(layer.self_attn.qkv_proj.weight.shape) == ((2 + 2 * 1) * 32, 64)
+        assert tuple(layer.self_attn.o_proj.weight.shape) == (64, 2 * 32)
+        assert tuple(layer.mlp.down_proj.weight.shape) == (64, 48)
+        assert r.kv_cache.shape[3] == 1                        # one KV head per rank
+        assert r.model.lm_head.weight.shape[0] == 384 // 2     # 331 padded to 2 x 64 multiples
+        out = eng.generate([[1, 2, 3, 4, 5], list(range(20))],
+                           SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+        assert [len(t) for t in out["token_ids"]] == [6, 6]
+    finally:
+        eng.exit()
+    assert not pg.is_rehearsal() and pg.tp_size() == 1
+    with pytest.raises(ValueError):
+        dataclasses.replace(_cfg(2, port), tp_shard=2).validate()

@@ -5,8 +5,9 @@
 
 ``--after X`` keeps only dispatches that start after the LAST dispatch whose name contains X
 (e.g. ``flash_prefill`` to isolate the decode phase).  ``--marker M --last-steps N`` keeps the
-dispatches of the last N "steps", where a step starts at every occurrence of marker kernel M
-with the largest per-step count (use the sampler kernel: one per step).
+dispatches of the last N "steps", where a step ends with every occurrence of marker kernel M
+(use the sampler kernel: one per step); ``--marker M --skip-steps S --first-steps N`` keeps steps
+S .. S+N-1 counted from the start of the trace (S >= 1).
 Prints busy time, wall span and the idle share (launch gaps) of the window.
 """
 import argparse
@@ -30,6 +31,9 @@ def main():
     ap.add_argument("--after", default=None)
     ap.add_argument("--marker", default=None)
     ap.add_argument("--last-steps", type=int, default=0)
+    ap.add_argument("--first-steps", type=int, default=0,
+                    help="with --marker: the N steps that follow the first --skip-steps steps")
+    ap.add_argument("--skip-steps", type=int, default=0)
     ap.add_argument("--top", type=int, default=14)
     a = ap.parse_args()
     rows = []
@@ -40,9 +44,12 @@ def main():
     if a.after:
         idx = max(i for i, r in enumerate(rows) if a.after in r[2])
         rows = rows[idx + 1:]
-    if a.marker and a.last_steps:
+    if a.marker and (a.last_steps or a.first_steps):
         marks = [i for i, r in enumerate(rows) if a.marker in r[2]]
-        marks = marks[-(a.last_steps + 1):]
+        if a.first_steps:        # step k ends at marks[k]: steps skip .. skip + n - 1
+            marks = marks[max(a.skip_steps - 1, 0):a.skip_steps + a.first_steps]
+        else:
+            marks = marks[-(a.last_steps + 1):]
         rows = rows[marks[0] + 1: marks[-1] + 1]
         steps = len(marks) - 1
     else:
