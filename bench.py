@@ -77,6 +77,30 @@ def make_config(args, model_name: str, world: int) -> EngineConfig:
         custom_all_reduce=bool(args.tp_shard and args.p2p)).validate()
 
 
+def _condense_smi(doc):
+    """Socket power and, per clock domain, (min, max) over the instances the tool lists."""
+    found = {}
+
+    def walk(node, path):
+        if isinstance(node, dict):
+            if "value" in node and isinstance(node["value"], (int, float)):
+                key = path.rstrip("_0123456789") if path[-1:].isdigit() else path
+                found.setdefault(key + (f" [{node.get('unit')}]" if node.get("unit") else ""), []).append(node["value"])
+                return
+            for k, v in node.items():
+                if k in ("min_clk", "max_clk"):
+                    continue
+                walk(v, k if k not in ("clk",) else path)
+        elif isinstance(node, list):
+            for v in node:
+                walk(v, path)
+    try:
+        walk(doc, "")
+        return {k: (v[0] if len(v) == 1 else [min(v), max(v)]) for k, v in found.items()}
+    except Exception:
+        return str(doc)[:600]
+
+
 def gpu_state() -> dict:
     """Clock / power readings of GPU 0 as the SMI tools report them, so that a slow number can be
     told from a slow box (boxes of one pool differ by 5-15 %).  Best effort: absent tools or
@@ -97,9 +121,9 @@ def gpu_state() -> dict:
             r = subprocess.run(argv, capture_output=True, text=True, timeout=20)
             if r.returncode == 0 and r.stdout.strip():
                 try:
-                    out[tool] = json.loads(r.stdout)
+                    out[tool] = _condense_smi(json.loads(r.stdout))
                 except ValueError:
-                    out[tool] = r.stdout.strip()[:1500]
+                    out[tool] = r.stdout.strip()[:600]
                 break
         except Exception:
             continue

@@ -452,7 +452,7 @@ int big_launch(BigArgs a, hipStream_t st) {
 
 // out[M, N_out] = x . W^T (+ bias)  [swiglu: W = [gate; up], N_out = N / 2].
 // K a multiple of 64 and >= 256; N a multiple of 256 (swiglu: N / 2 a multiple of 128); x rows
-// and out rows 16-byte aligned; x, W and out below 4 GiB each.
+// and out rows 16-byte aligned; x, W and out below 2 GiB each (32-bit buffer offsets).
 extern "C" int mvl_big_gemm(const void* x, long x_stride, const void* w, const void* bias,
                             void* out, long o_stride, int M, int N, int K, int swiglu, int dtype,
                             void* stream) {

@@ -65,6 +65,10 @@ class Sequence:
     def token_array(self, start: int, end: int) -> np.ndarray:
         """``token_ids[start:end]`` as an int32 array (a view of a cached image that is extended
         when generated tokens fall into the range, e.g. a re-prefill after preemption)."""
+        if end - start == 1 and end == self.num_tokens:
+            # the newest token alone (a decode rider of a mixed step): no need to bring the
+            # image up to date, which would convert the whole list for every rider every step
+            return np.array([self.last_token], dtype=np.int32)
         img = getattr(self, "_np_tokens", None)
         if img is None or img.size < end:
             img = self._np_tokens = np.asarray(self.token_ids[:max(end, self.num_tokens)], dtype=np.int32)

@@ -185,6 +185,13 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
     T = qkv.shape[0]
     qs, ks = num_heads * head_dim, num_kv_heads * head_dim
     assert qkv.shape[1] == qs + 2 * ks
+    # the kernel moves 16 bytes per lane on the qkv rows, the norm weights and the cache rows
+    if qkv.data_ptr() % 16 or (T > 1 and qkv.stride(0) % 8) or head_dim % 16:
+        raise ValueError("qk_norm_rope_store needs 16-byte aligned qkv rows (row stride a multiple "
+                         "of 8 elements) and head_dim a multiple of 16")
+    for wgt in (q_weight, k_weight):
+        if wgt is not None and (wgt.data_ptr() % 16 or not wgt.is_contiguous()):
+            raise ValueError("q/k norm weights must be contiguous and 16-byte aligned")
     if cos_sin.dtype != torch.float32:
         raise TypeError("cos/sin table must be fp32")
     positions = _i32(positions)
@@ -194,6 +201,11 @@ def qk_norm_rope_store(qkv: torch.Tensor, positions: torch.Tensor, cos_sin: torc
         assert _cache_strides(v_cache) == (sb, st, sh)
         slot_mapping = _i32(slot_mapping)
         bs = k_cache.shape[1]
+        unit = 8 if _kv_fp8(k_cache) else 16          # bytes per access on a cache row
+        esz = k_cache.element_size()
+        if any((v * esz) % unit for v in (sb, st, sh)) or k_cache.data_ptr() % unit \
+                or v_cache.data_ptr() % unit:
+            raise ValueError(f"KV cache rows must be {unit}-byte aligned (strides {sb}, {st}, {sh})")
     else:
         sb = st = sh = 0
         bs = 1
@@ -334,7 +346,9 @@ def decode_num_splits(batch: int, num_kv_heads: int, max_context_len: Optional[i
     """Context splits so that ~2 workgroups per CU exist even at batch 1; never more splits
     than 128-token chunks of the longest context."""
     wgs = max(batch * num_kv_heads, 1)
-    n = max(1, min(32, 512 // wgs))
+    # one workgroup per CU or more: no split (batch 256 x 1 KV head at 1024 tokens: 24.5 us
+    # unsplit, 27 us in two splits; what the second split adds is its merge, not bandwidth)
+    n = 1 if wgs >= 256 else max(1, min(32, 512 // wgs))
     if max_context_len is not None:
         n = max(1, min(n, (max_context_len + 127) // 128))
     return n
@@ -350,15 +364,19 @@ DECODE_TICKET_WORDS = 1 << 16
 def decode_ticket_words(device: torch.device, need: int) -> torch.Tensor:
     """The device's ticket buffer (at least ``need`` ints).  It is allocated on first use, which
     must not happen inside a graph capture (the memory would belong to the graph's pool): the
-    model runner calls this at start-up."""
+    model runner calls this at start-up.  A captured graph has the buffer's address baked in, so
+    a buffer is never freed or replaced: a caller that needs more words than exist gets a new,
+    larger buffer for ITS launches while the old one stays alive for the graphs that use it."""
     idx = device.index if device.index is not None else torch._C._cuda_getDevice()
-    buf = _DECODE_TICKETS.get(idx)
-    if buf is None or buf.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
-            raise RuntimeError("the decode kernel's ticket buffer must exist before graph capture: "
-                               "call hip.decode_ticket_words(device, n) first")
-        buf = _DECODE_TICKETS[idx] = torch.zeros(max(need, DECODE_TICKET_WORDS), dtype=torch.int32,
-                                                 device=device)
+    bufs = _DECODE_TICKETS.setdefault(idx, [])
+    for buf in bufs:
+        if buf.numel() >= need:
+            return buf
+    if torch.cuda.is_current_stream_capturing():
+        raise RuntimeError("the decode kernel's ticket buffer must exist before graph capture: "
+                           "call hip.decode_ticket_words(device, n) first")
+    buf = torch.zeros(max(need, DECODE_TICKET_WORDS), dtype=torch.int32, device=device)
+    bufs.append(buf)                 # earlier (smaller) buffers stay referenced here for good
     return buf
 
 
@@ -641,6 +659,10 @@ def mid_gemm_candidates(m: int, n: int, k: int, swiglu: bool = False):
             if s not in seen:
                 seen.add(s)
                 out.append((bn, s))
+        # short K (a tensor-parallel rank's o / down): one launch without a K split may beat two
+        # (GEMM + slice sum) even though it leaves CUs idle
+        if ksteps <= 32 and 1 not in seen:
+            out.append((bn, 1))
     return out
 
 
@@ -870,7 +892,8 @@ BIG_MIN_ROWS = 257                    # below this the weight-streaming kernels 
 def big_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> bool:
     """Operands the 256 x 256-tile kernel can take: 2-D 16-bit row-major x (row stride a multiple
     of 8 elements) and contiguous weights of the same dtype, K a multiple of 64 and >= 256, the
-    output width (per SwiGLU half: N / 2) a multiple of 256 (128), operands below 4 GiB."""
+    output width (per SwiGLU half: N / 2) a multiple of 256 (128), every operand below 2 GiB (the
+    kernel addresses them with 32-bit buffer offsets and refuses anything larger)."""
     if x.dim() != 2 or weight.dim() != 2 or x.dtype not in _DT or weight.dtype != x.dtype:
         return False
     M, K = x.shape
@@ -885,7 +908,7 @@ def big_gemm_ok(x: torch.Tensor, weight: torch.Tensor, swiglu: bool = False) -> 
     elif N % 256:
         return False
     n_out = N // 2 if swiglu else N
-    return (M * x.stride(0) * 2 < (1 << 32) and N * K * 2 < (1 << 32)
+    return (M * x.stride(0) * 2 < (1 << 31) and N * K * 2 < (1 << 31)
             and M * n_out * 2 < (1 << 31) and x.data_ptr() % 16 == 0)
 
 
@@ -930,7 +953,10 @@ def tune_big_gemm(weights, swiglu: bool = False, rows=BIG_ROW_BUCKETS, margin: f
         ker = lambda xx, w: big_linear(xx, w, None, swiglu)
         reps = max(1, min(8, int(2e11 / (2.0 * m * n * k))))
         t_lib = _graph_time_ms(lib, x, weights, reps)
-        t_ker = _graph_time_ms(ker, x, weights, reps)
+        try:
+            t_ker = _graph_time_ms(ker, x, weights, reps)
+        except (RuntimeError, ValueError):        # the kernel refuses the operands: library
+            t_ker = float("inf")
         use = t_ker < t_lib * margin
         _BIG_CHOICE[(big_row_bucket(m), n, k, swiglu)] = use
         out[m] = (round(t_lib * 1e3, 1), round(t_ker * 1e3, 1), use)

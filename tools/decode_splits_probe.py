@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Paged decode attention at small batch and long context against the number of context splits
-(the default rule gives min(32, 512 / (batch x KV heads)) splits).  Qwen3-8B heads, bf16, block 256.
+(the default rule gives min(32, 512 / (batch x KV heads)) splits).  Qwen3-8B heads by default, bf16,
+block 256.
 
-    python tools/decode_splits_probe.py
+    python tools/decode_splits_probe.py [--hq 4 --hkv 1 --cases 256x1024,64x1024 --splits 1,2,3,4,6,8]
 """
 import math
 import os
@@ -27,9 +28,19 @@ def timeit(fn, iters=50):
 
 
 def main():
-    hq, hkv, d, bs = 32, 8, 128, 256
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--hq", type=int, default=32)
+    ap.add_argument("--hkv", type=int, default=8)
+    ap.add_argument("--cases", default="1x32768,1x32768,1x8192,2x16384,4x8192,8x16384,16x4096",
+                    help="comma list of BATCHxCONTEXT")
+    ap.add_argument("--splits", default="8,16,32,48,64")
+    a = ap.parse_args()
+    hq, hkv, d, bs = a.hq, a.hkv, 128, 256
     scale = 1 / math.sqrt(d)
-    for B, ctx in ((1, 32768), (1, 32768), (1, 8192), (2, 16384), (4, 8192), (8, 16384), (16, 4096)):
+    cases = [tuple(int(v) for v in c.split("x")) for c in a.cases.split(",")]
+    extra = {int(v) for v in a.splits.split(",")}
+    for B, ctx in cases:
         nblk = (ctx + bs - 1) // bs
         kc = torch.randn(B * nblk, hkv, bs, d, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
         vc = torch.randn(B * nblk, hkv, bs, d, device="cuda", dtype=torch.bfloat16).permute(0, 2, 1, 3)
@@ -39,7 +50,7 @@ def main():
         by = 2 * B * ctx * hkv * d * 2
         dflt = hip.decode_num_splits(B, hkv, ctx)
         row = []
-        for ns in sorted({dflt, 8, 16, 32, 48, 64}):
+        for ns in sorted({dflt} | extra):
             if ns > (ctx + 127) // 128:
                 continue
             # replayed from a graph: at these sizes the launch path would dominate

@@ -5,28 +5,24 @@
 # with RCCL (single-member group) and, decode only, with the peer-to-peer kernels in loop-back form.
 # Output: gpurun_out/shard/*.txt (trace summaries) and *.json (bench lines).
 #   tools/tp_shard_rehearsal.sh [model] [tp degrees...]      default: qwen3-8b 2 4 8
+# Extra bench.py arguments for every run: env BENCH_ARGS (e.g. "--seq-len 32768 --prefill-tokens 32768 --batch 8")
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/shard; mkdir -p $O
 MODEL=${1:-qwen3-8b}; shift; TPS=${@:-2 4 8}
-W=3; K=8
+W=${W:-3}; K=${K:-8}; LAST=${LAST:-6}
 run() {  # name, extra bench args...
   local name=$1; shift
-  timeout -k 10 420 rocprofv3 --kernel-trace --output-format csv -d $O/$name -- python3 $R/bench.py \
-      --model $MODEL --second-model "" --steps $K --warmup $W "$@" > $O/$name.json 2> $O/$name.err \
+  timeout -k 10 480 rocprofv3 --kernel-trace --output-format csv -d $O/$name -- python3 $R/bench.py \
+      --model $MODEL --second-model "" --steps $K --warmup $W $BENCH_ARGS "$@" > $O/$name.json 2> $O/$name.err \
       || { echo "$name FAILED"; tail -8 $O/$name.err; return 1; }
   f=$(ls $O/$name/*/*_kernel_trace.csv | head -1)
-  echo "== $name: $(python3 -c "import json,sys; d=json.loads(open('$O/$name.json').read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('prefill_ms_per_step','decode_ms_per_step','p2p_allreduce','gemm_choice_source')})")"
+  echo "== $name: $(python3 -c "import json,sys; d=json.loads(open('$O/$name.json').read().strip().splitlines()[-1]); print({k: d.get(k) for k in ('prefill_ms_per_step','decode_ms_per_step','p2p_allreduce','gemm_choice_source','kv_blocks')})")"
+  python3 $R/tools/prof_summary.py $f --marker sample_kernel --last-steps $LAST --top 20 > $O/$name.txt 2>&1
+  head -24 $O/$name.txt
+  rm -rf $O/$name
 }
 for tp in $TPS; do
-  run ${MODEL}_tp${tp}_both --tp-shard $tp --mode both || exit 1
-  f=$(ls $O/${MODEL}_tp${tp}_both/*/*_kernel_trace.csv | head -1)
-  python3 $R/tools/prof_summary.py $f --marker sample_kernel --skip-steps $((W+1)) --first-steps $((K-1)) --top 18 > $O/${MODEL}_tp${tp}_prefill.txt 2>&1
-  python3 $R/tools/prof_summary.py $f --marker sample_kernel --last-steps 6 --top 18 > $O/${MODEL}_tp${tp}_decode.txt 2>&1
-  head -22 $O/${MODEL}_tp${tp}_prefill.txt; head -22 $O/${MODEL}_tp${tp}_decode.txt
-  rm -rf $O/${MODEL}_tp${tp}_both
-  run ${MODEL}_tp${tp}_decode_p2p --tp-shard $tp --p2p --mode decode || exit 1
-  f=$(ls $O/${MODEL}_tp${tp}_decode_p2p/*/*_kernel_trace.csv | head -1)
-  python3 $R/tools/prof_summary.py $f --marker sample_kernel --last-steps 6 --top 18 > $O/${MODEL}_tp${tp}_decode_p2p.txt 2>&1
-  head -22 $O/${MODEL}_tp${tp}_decode_p2p.txt
-  rm -rf $O/${MODEL}_tp${tp}_decode_p2p
+  run ${MODEL}_tp${tp}_prefill --tp-shard $tp --mode prefill || exit 1
+  run ${MODEL}_tp${tp}_decode --tp-shard $tp --mode decode || exit 1
+  if [ -z "$NO_P2P" ]; then run ${MODEL}_tp${tp}_decode_p2p --tp-shard $tp --p2p --mode decode || exit 1; fi
 done
