@@ -146,16 +146,22 @@ class EngineConfig:
     dist_backend: str = "auto"         # 'auto' | 'nccl' | 'gloo'
     # decode graphs
     graph_batch_sizes: Optional[list] = None
-    # prefill steps of at most prefill_graph_max_seqs sequences and prefill_graph_max_tokens new
-    # tokens replay a hipGraph too (one per token bucket; 0 = always launch prefill eagerly).
-    # Wider limits are accepted (up to 4096 tokens) but measured slower: a captured step sizes
-    # its attention grid for the worst case of its bucket, and from ~1.5k tokens an eager step
-    # is GPU-bound anyway (Qwen3-0.6B, 4000 tokens: 7.5 ms replayed vs 6.0 ms eager)
+    # Prefill steps replay hipGraphs too (an eager step costs ~6 ms of host launches however
+    # small it is).  One graph per (token bucket, sequence-count bucket): the attention kernel
+    # takes its work from a list in device memory, so a graph's launch shapes depend on the
+    # step's budgets only.  Graphs for steps of at most prefill_graph_max_tokens new tokens and
+    # prefill_graph_max_seqs sequences are captured at start-up; with prefill_graph_lazy every
+    # other pure prefill step shape is captured the first time it occurs (that step runs
+    # eagerly on the graph's static buffers and is then recorded), up to
+    # prefill_graph_max_graphs graphs.  prefill_graph_max_tokens = 0: always launch eagerly.
+    # Mixed prefill + decode steps are not captured.
     prefill_graph_max_tokens: int = 1024
     prefill_graph_max_seqs: int = 8
+    prefill_graph_lazy: bool = True
+    prefill_graph_max_graphs: int = 96
 
     def prefill_graph_limits(self) -> tuple:
-        """(max tokens, max sequences) of a graph-replayed prefill step."""
+        """(max tokens, max sequences) of the prefill graphs captured at start-up."""
         return min(self.prefill_graph_max_tokens, 4096), max(1, self.prefill_graph_max_seqs)
     log_stats: bool = False
     tuned_gemms: bool = True           # load the shipped TunableOp table for library GEMMs

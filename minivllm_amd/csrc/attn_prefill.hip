@@ -60,6 +60,11 @@ struct PrefillArgs {
     int n_items;                               // Q-tile items per (sequence, head): n_qtiles, or pairs of them
     int pair;                                  // 0: an item is one Q tile; g > 0: g pairs (n_qtiles - 1 - p, p)
     int total_wg;
+    // optional work list (n_items slots): entry (sequence << 16 | pair index) or -1 for a slot
+    // without work.  The grid is then n_items x Hq workgroups whatever the sequence lengths are,
+    // which is what a captured graph needs: the launch shape depends on the step's token and
+    // sequence BUDGET only, the host writes the real work of each replay into the list.
+    const int* items;
     // optional: q holds the raw projection and the kernel applies the per-head RMSNorm (weight
     // q_w, may be null) and the rotary embedding (fp32 table [position][D]: cos of the D/2
     // pairs, then sin) to its Q rows while it loads them; null cos_sin: q is used as it is
@@ -116,9 +121,18 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     }
     const int G = a.Hq / a.Hkv;
     const int g = id % G;              id /= G;
-    const int qti = id % a.n_items;    id /= a.n_items;
-    const int kvh = id % a.Hkv;
-    const int b = id / a.Hkv;
+    int qti = id % a.n_items;          id /= a.n_items;
+    int kvh, b;
+    if (a.items != nullptr) {
+        kvh = id;                                        // grid = G x n_items x Hkv
+        const int it = a.items[qti];
+        if (it < 0) return;                              // a slot of the budget this step does not use
+        b = it >> 16;
+        qti = it & 0xffff;
+    } else {
+        kvh = id % a.Hkv;
+        b = id / a.Hkv;
+    }
     const int head = kvh * G + g;
 
     const int q_start = a.cu_q[b], q_len = a.cu_q[b + 1] - q_start;
@@ -129,7 +143,10 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     // under the causal mask tile i attends to i + 1 key blocks, so the pair (n - 1 - p, p) always
     // costs n + 1 of them; every workgroup of a sequence then runs equally long and the fixed
     // cost of a workgroup (launch, ramp-up, drain) is paid once per 2 g tiles.
-    const int n_pairs = (a.n_qtiles + 1) >> 1;
+    // with a work list the pairs are formed per sequence (from its own tile count), without one
+    // from the longest sequence's (shorter ones skip the tiles they do not have)
+    const int n_qtiles = a.items != nullptr ? (q_len + kBM - 1) / kBM : a.n_qtiles;
+    const int n_pairs = (n_qtiles + 1) >> 1;
     const int n_pass = a.pair ? 2 * a.pair : 1;
 #pragma unroll 1
     for (int pass = 0; pass < n_pass; ++pass) {
@@ -137,10 +154,10 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     if (a.pair) {
         const int p = qti * a.pair + (pass >> 1);
         if (p >= n_pairs) break;
-        if ((pass & 1) && 2 * p == a.n_qtiles - 1) continue;     // the middle tile of an odd count: once
-        qt = (pass & 1) ? p : a.n_qtiles - 1 - p;
+        if ((pass & 1) && 2 * p == n_qtiles - 1) continue;       // the middle tile of an odd count: once
+        qt = (pass & 1) ? p : n_qtiles - 1 - p;
     } else {
-        qt = a.n_qtiles - 1 - qti;                       // heaviest tiles first
+        qt = n_qtiles - 1 - qti;                         // heaviest tiles first
     }
     const int q0 = qt * kBM;
     if (q0 >= q_len) continue;                           // uniform for the workgroup
@@ -622,14 +639,17 @@ int launch_prefill(PrefillArgs a, hipStream_t st) {
 // k_stride_h), cu_k may equal cu_q.  paged == 1: k/v are caches addressed by
 // (block stride cs_b, token stride k_stride_t, head stride k_stride_h) through block_tables;
 // kv_fp8 != 0: the caches hold OCP fp8 (e4m3) bytes (strides in bytes).
+// items (optional, n_item_slots entries): the step's work list, see PrefillArgs; max_q_len is
+// then only required to be positive.
 extern "C" int mvl_flash_attention_prefill(
         const void* q, long q_stride_t, long q_stride_h, const void* k, const void* v,
         long k_stride_t, long k_stride_h, long cs_b, void* out, long o_stride_t, long o_stride_h,
         const int* cu_q, const int* cu_k, const int* block_tables, int bt_stride, int block_size,
         float scale, int B, int Hq, int Hkv, int D, int max_q_len, int paged, int dtype,
         const int* positions, const float* cos_sin, const void* q_w, float eps, int kv_fp8,
-        void* stream) {
+        const int* items, int n_item_slots, void* stream) {
     if (B == 0 || max_q_len <= 0) return 0;
+    if (items != nullptr && (n_item_slots <= 0 || B > 32767)) return items != nullptr && n_item_slots == 0 ? 0 : -1;
     if ((D != 64 && D != 128) || Hq % Hkv != 0) return -1;
     if (paged && (block_size & (block_size - 1))) return -1;
     if (kv_fp8 && !paged) return -1;
@@ -656,6 +676,12 @@ extern "C" int mvl_flash_attention_prefill(
     a.pair = pair_env ? atoi(pair_env) : 1;
     a.n_items = a.pair ? (n_pairs + a.pair - 1) / a.pair : a.n_qtiles;
     a.total_wg = B * Hq * a.n_items;
+    a.items = items;
+    if (items != nullptr) {          // one heavy / light pair of one sequence per slot
+        a.pair = 1;
+        a.n_items = n_item_slots;
+        a.total_wg = Hq * n_item_slots;
+    }
     if (cos_sin != nullptr && positions == nullptr) return -1;
     a.positions = positions; a.cos_sin = cos_sin; a.q_w = (const uint16_t*)q_w; a.eps = eps;
     // one uniform base per K/V tile: blocks of a multiple of 64 tokens, tile strides within 31 bits

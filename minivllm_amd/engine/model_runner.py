@@ -361,13 +361,16 @@ class ModelRunner:
         self._dec_dev = torch.zeros(self._dec_words, dtype=torch.int32, device=self.device)
         self._pre_host = None
         self._pre_dev = None
-        # a prefill step of a few sequences and few tokens (short prompts, a new chat turn
-        # behind a cached prefix) replays a hipGraph as decode does: fixed layout, one buffer
-        self.prefill_graphs: Dict[int, "torch.cuda.CUDAGraph"] = {}
-        self._pg_out: Dict[int, torch.Tensor] = {}
-        self._pg_logits: Dict[int, torch.Tensor] = {}      # static logits of each prefill graph
+        # prefill steps replay hipGraphs as decode steps do: fixed layout, one static buffer.
+        # Key = (token bucket, sequence-count bucket); small ones are captured at start-up, the
+        # others the first time they occur (``_prefill_graph_key`` / ``_run_prefill_graph``)
+        self.prefill_graphs: Dict[tuple, "torch.cuda.CUDAGraph"] = {}
+        self._pg_out: Dict[tuple, torch.Tensor] = {}
+        self._pg_logits: Dict[tuple, torch.Tensor] = {}    # static logits of each prefill graph
+        self._pg_failed: set = set()                       # shapes whose capture failed: eager
         self._graph_logits: Dict[int, torch.Tensor] = {}   # ... and of each decode graph
         self._last_logits: Optional[torch.Tensor] = None
+        self._last_step_logits: Optional[torch.Tensor] = None
         self.prefill_graph_replays = 0
         pg_max, self.pg_max_seqs = cfg.prefill_graph_limits()
         if not self.on_gpu or cfg.enforce_eager:
@@ -375,16 +378,26 @@ class ModelRunner:
         pg_max = int(os.environ.get("MINIVLLM_PREFILL_GRAPH_MAX", pg_max))
         pg_max = min(pg_max, 4096, cfg.max_num_batched_tokens)
         self.pg_max_seqs = min(self.pg_max_seqs, cfg.max_num_sequences)
-        # = the prefill token buckets up to pg_max
+        # = the prefill token buckets up to pg_max (captured at start-up)
         self._pg_sizes = sorted({prefill_token_bucket(t) for t in range(64, pg_max + 1, 64)
                                  if prefill_token_bucket(t) <= pg_max})
+        self._pg_lazy = bool(pg_max and cfg.prefill_graph_lazy
+                             and os.environ.get("MINIVLLM_NO_LAZY_PREFILL_GRAPHS") != "1")
+        # sequence-count buckets: a graph serves any step with at most that many sequences (its
+        # attention grid and LM-head rows are sized for the bucket)
+        S = cfg.max_num_sequences
+        self._pg_seq_buckets = sorted({min(self.pg_max_seqs, S), min(32, S), min(128, S), S})
         self._pg_off = {}
         if self._pg_sizes:
-            tmax, off = self._pg_sizes[-1], 0
-            S = self.pg_max_seqs
+            from minivllm_amd.ops import hip
+            tmax = prefill_token_bucket(cfg.max_num_batched_tokens) if self._pg_lazy else self._pg_sizes[-1]
+            smax = S if self._pg_lazy else self.pg_max_seqs
+            self._pg_tmax, self._pg_smax, off = tmax, smax, 0
             for name, n in (("input_ids", tmax), ("positions", tmax), ("slot_mapping", tmax),
-                            ("cu_seqlens_q", S + 1), ("cu_seqlens_k", S + 1), ("temperatures", S),
-                            ("misc", 4), ("block_tables", S * MB)):
+                            ("cu_seqlens_q", smax + 1), ("cu_seqlens_k", smax + 1),
+                            ("temperatures", smax), ("misc", 4),
+                            ("prefill_items", hip.prefill_item_slots(tmax, smax)),
+                            ("block_tables", smax * MB)):
                 self._pg_off[name] = (off, n)
                 off += (n + 3) // 4 * 4
             self._pg_host = torch.zeros(off, dtype=torch.int32, pin_memory=True)
@@ -450,6 +463,7 @@ class ModelRunner:
         self._pg_out = {}
         self._graph_out = {}
         self._pg_logits, self._graph_logits, self._last_logits = {}, {}, None
+        self._last_step_logits = None
         self.graph_pool = None
         for layer in self.model.model.layers:
             layer.self_attn.attn.k_cache = layer.self_attn.attn.v_cache = None
@@ -617,6 +631,10 @@ class ModelRunner:
                       block_tables=tables)
         if num_decode:
             arrays["context_lens"] = np.asarray([s.num_tokens for s in seqs[first_decode:]], np.int32)
+        if self.on_gpu:
+            # the attention kernel's work list: one entry per pair of query tiles of a prompt
+            from minivllm_amd.ops import hip
+            arrays["prefill_items"] = hip.prefill_work_items(lens[:first_decode], ends[:first_decode])
         self._add_filter_arrays(arrays, seqs)
         return Batch(is_prefill=True, num_seqs=B, num_tokens=int(input_ids.size),
                      max_seqlen_q=max_q, max_seqlen_k=max_k, has_prefix=has_prefix,
@@ -833,6 +851,7 @@ class ModelRunner:
         for name, n in (("input_ids", T), ("positions", T), ("slot_mapping", T),
                         ("cu_seqlens_q", B + 1), ("cu_seqlens_k", B + 1), ("temperatures", B),
                         ("misc", 4), ("context_lens", b.num_decode_seqs),
+                        ("prefill_items", a["prefill_items"].size if "prefill_items" in a else 0),
                         ("block_tables", B * MB)):
             layout[name] = (off, n)
             off += al(n)
@@ -854,6 +873,7 @@ class ModelRunner:
                     cu_seqlens_k=v("cu_seqlens_k"),
                     temperatures=v("temperatures").view(torch.float32),
                     step=v("misc"), context_lens=v("context_lens"),
+                    prefill_items=v("prefill_items") if "prefill_items" in a else None,
                     block_tables=v("block_tables").view(B, MB))
 
     def _fill_decode_host(self, b: Batch, padded_bs: int) -> None:
@@ -931,10 +951,9 @@ class ModelRunner:
 
     # -------------------------------------------------------------- execute
     def execute(self, b: Batch, warmup: bool = False) -> Optional[List[int]]:
-        if (b.is_prefill and not warmup and b.num_seqs <= self.pg_max_seqs
-                and not b.num_decode_seqs and b.num_tokens in self.prefill_graphs):
-            tokens = self._replay_prefill_graph(b)
-            logits = self._pg_logits.get(b.num_tokens)
+        pg_key = self._prefill_graph_key(b) if b.is_prefill and not warmup else None
+        if pg_key is not None:
+            tokens, logits = self._run_prefill_graph(b, pg_key)
         elif b.is_prefill:
             t = self._upload_prefill(b)
             set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
@@ -944,7 +963,8 @@ class ModelRunner:
                         positions=t["positions"], num_seqs=b.num_seqs, has_prefix=b.has_prefix,
                         num_decode_seqs=b.num_decode_seqs, num_prefill_tokens=b.num_prefill_tokens,
                         context_lens=t["context_lens"] if b.num_decode_seqs else None,
-                        max_context_len=b.max_context_len, total_k_tokens=b.num_prefill_k_tokens)
+                        max_context_len=b.max_context_len, total_k_tokens=b.num_prefill_k_tokens,
+                        prefill_items=None if warmup else t["prefill_items"])
             tokens = self._forward_and_sample(t)
             logits = self._last_logits
         else:
@@ -967,6 +987,7 @@ class ModelRunner:
                 tokens = self._forward_and_sample(t)
                 logits = self._last_logits
         reset_context()
+        self._last_step_logits = logits          # this step's (local) logits, whichever path ran
         if not warmup and "top_k" in b.arrays:
             tokens = self._resample_filtered(b, tokens, logits)
         if warmup or tokens is None or self.rank != 0:
@@ -1147,30 +1168,79 @@ class ModelRunner:
         torch.cuda.synchronize()
         self._capture_prefill_graphs()
 
-    def _pg_tensors(self, tb: int) -> dict:
+    # ------------------------------------------------------------ prefill graphs
+    def _pg_tensors(self, tb: int, sb: int) -> dict:
         d = self._pg_dev
+        MB = self.max_blocks_per_seq
+        from minivllm_amd.ops import hip
 
         def v(name, n=None):
             off, size = self._pg_off[name]
             return d[off:off + (size if n is None else n)]
         return dict(input_ids=v("input_ids", tb), positions=v("positions", tb),
-                    slot_mapping=v("slot_mapping", tb), cu_seqlens_q=v("cu_seqlens_q"),
-                    cu_seqlens_k=v("cu_seqlens_k"),
-                    temperatures=v("temperatures").view(torch.float32), step=v("misc"),
-                    block_tables=v("block_tables").view(self.pg_max_seqs,
-                                                        self.max_blocks_per_seq))
+                    slot_mapping=v("slot_mapping", tb), cu_seqlens_q=v("cu_seqlens_q", sb + 1),
+                    cu_seqlens_k=v("cu_seqlens_k", sb + 1),
+                    temperatures=v("temperatures", sb).view(torch.float32), step=v("misc"),
+                    prefill_items=v("prefill_items", hip.prefill_item_slots(tb, sb)),
+                    block_tables=v("block_tables", sb * MB).view(sb, MB))
+
+    def _prefill_graph_key(self, b: Batch):
+        """(token bucket, sequence bucket) of the graph that serves this prefill step, or None
+        when the step launches eagerly: mixed steps, steps beyond the static buffers, shapes
+        whose capture failed, and - without lazy capture - anything not captured at start-up."""
+        if not self._pg_off or b.num_decode_seqs or self.enforce_eager:
+            return None
+        if b.num_tokens > self._pg_tmax or b.num_seqs > self._pg_smax \
+                or b.arrays["block_tables"].shape[1] > self.max_blocks_per_seq:
+            return None
+        sb = next(x for x in self._pg_seq_buckets if x >= b.num_seqs)
+        key = (b.num_tokens, sb)
+        if key in self.prefill_graphs:
+            return key
+        if (not self._pg_lazy or key in self._pg_failed
+                or len(self.prefill_graphs) >= self.cfg.prefill_graph_max_graphs
+                or "prefill_items" not in b.arrays):
+            return None
+        return key
+
+    def _pg_step(self, t: dict, tb: int, sb: int):
+        set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
+                    max_seqlen_q=tb, max_seqlen_k=self.cfg.max_model_length,
+                    slot_mapping=t["slot_mapping"], block_tables=t["block_tables"],
+                    positions=t["positions"], num_seqs=sb, has_prefix=True,
+                    prefill_items=t["prefill_items"])
+        out = self._forward_and_sample(t)
+        reset_context()
+        return out
+
+    def _capture_prefill_graph(self, key: tuple, warm_up: bool) -> None:
+        """Record one prefill step on the static buffers.  ``warm_up``: run it once eagerly
+        first (start-up captures; a lazy capture has just run the real step there)."""
+        tb, sb = key
+        t = self._pg_tensors(tb, sb)
+        if warm_up:
+            self._pg_step(t, tb, sb)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
+            out = self._pg_step(t, tb, sb)
+        if self.graph_pool is None:
+            self.graph_pool = g.pool()
+        self.prefill_graphs[key] = g
+        self._pg_out[key] = out
+        self._pg_logits[key] = self._last_logits
 
     def _capture_prefill_graphs(self) -> None:
-        """One graph per token bucket for a prefill step of up to ``pg_max_seqs``
-        sequences (any cached prefix: attention goes through the block table and reads the
-        lengths from device memory; unused sequence slots have length 0).  An eager prefill
-        step costs ~6 ms of host launches however small it is; replayed, a short prompt is
-        bound by the GPU again."""
+        """Start-up captures: one graph per token bucket up to ``prefill_graph_max_tokens`` for
+        steps of up to ``prefill_graph_max_seqs`` sequences (short prompts, a new chat turn
+        behind a cached prefix, a chunk of a long prompt: the steps a server sees most).  Any
+        cached prefix is fine: attention goes through the block table and reads the lengths
+        from device memory; unused sequence slots have length 0."""
         if not self._pg_sizes:
             return
         host = self._pg_host.numpy()
         host[:] = 0
-        for name in ("slot_mapping", "block_tables"):
+        for name in ("slot_mapping", "block_tables", "prefill_items"):
             o, n = self._pg_off[name]
             host[o:o + n] = -1
         # a harmless one-token sequence (reads block 0, writes no KV: slot -1) + empty slots
@@ -1178,53 +1248,68 @@ class ModelRunner:
             o, n = self._pg_off[name]
             host[o + 1:o + n] = 1
         host[self._pg_off["block_tables"][0]] = 0
+        host[self._pg_off["prefill_items"][0]] = 0           # sequence 0, pair 0
         self._pg_dev.copy_(self._pg_host)
         for tb in reversed(self._pg_sizes):
-            t = self._pg_tensors(tb)
-
-            def step():
-                set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
-                            max_seqlen_q=tb, max_seqlen_k=self.cfg.max_model_length,
-                            slot_mapping=t["slot_mapping"], block_tables=t["block_tables"],
-                            positions=t["positions"], num_seqs=self.pg_max_seqs,
-                            has_prefix=True)
-                out = self._forward_and_sample(t)
-                reset_context()
-                return out
-            step()
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
-                out = step()
-            self.prefill_graphs[tb] = g
-            self._pg_out[tb] = out
-            self._pg_logits[tb] = self._last_logits
+            self._capture_prefill_graph((tb, self._pg_seq_buckets[0]), warm_up=True)
         torch.cuda.synchronize()
 
-    def _replay_prefill_graph(self, b: Batch) -> torch.Tensor:
+    def _fill_prefill_graph_inputs(self, b: Batch, key: tuple) -> None:
         a = b.arrays
-        tb, B, S = b.num_tokens, b.num_seqs, self.pg_max_seqs
-        MB = self.max_blocks_per_seq
+        tb, sb = key
+        B, MB = b.num_seqs, self.max_blocks_per_seq
+        from minivllm_amd.ops import hip
         host = self._pg_host.numpy()
         for name in ("input_ids", "positions", "slot_mapping"):
             o, _ = self._pg_off[name]
             host[o:o + tb] = a[name]
         for name in ("cu_seqlens_q", "cu_seqlens_k"):       # unused slots: zero-length sequences
-            o, n = self._pg_off[name]
+            o, _ = self._pg_off[name]
             host[o:o + B + 1] = a[name]
-            host[o + B + 1:o + n] = a[name][-1]
-        o, n = self._pg_off["temperatures"]
+            host[o + B + 1:o + sb + 1] = a[name][-1]
+        o, _ = self._pg_off["temperatures"]
         host[o:o + B] = a["temperatures"].astype(np.float32).view(np.int32)
-        host[o + B:o + n] = 0
+        host[o + B:o + sb] = 0
         host[self._pg_off["misc"][0]] = b.step
-        o, n = self._pg_off["block_tables"]
-        tab = host[o:o + n].reshape(S, MB)
+        o, _ = self._pg_off["prefill_items"]
+        slots = hip.prefill_item_slots(tb, sb)
+        items = a["prefill_items"]
+        host[o:o + items.size] = items
+        host[o + items.size:o + slots] = -1
+        o, _ = self._pg_off["block_tables"]
+        tab = host[o:o + sb * MB].reshape(sb, MB)
         mb = a["block_tables"].shape[1]
-        if mb > MB:
-            raise RuntimeError("sequence uses more KV blocks than max_model_length allows")
         tab[:] = -1
         tab[:B, :mb] = a["block_tables"]
         self._pg_dev.copy_(self._pg_host, non_blocking=True)
-        self.prefill_graphs[tb].replay()
-        self.prefill_graph_replays += 1
-        return self._pg_out[tb][:B]
+
+    def _run_prefill_graph(self, b: Batch, key: tuple):
+        """Replay the step's graph; returns (tokens, the step's logits).  A shape seen for the
+        first time runs eagerly on the graph's static buffers (that IS this step) and is
+        recorded afterwards for the next time.  A capture that fails leaves the step done and
+        the shape marked as eager-only."""
+        self._fill_prefill_graph_inputs(b, key)
+        B = b.num_seqs
+        if key in self.prefill_graphs:
+            self.prefill_graphs[key].replay()
+            self.prefill_graph_replays += 1
+            return self._pg_out[key][:B], self._pg_logits[key]
+        tb, sb = key
+        tokens = self._pg_step(self._pg_tensors(tb, sb), tb, sb)
+        tokens = tokens[:B].clone() if tokens is not None else None
+        logits = self._last_logits
+        try:
+            self._capture_prefill_graph(key, warm_up=False)
+        except Exception as e:                   # noqa: BLE001
+            self._pg_failed.add(key)
+            for d in (self.prefill_graphs, self._pg_out, self._pg_logits):
+                d.pop(key, None)
+            if self.rank == 0:
+                print(f"[runner] prefill graph {key} could not be captured ({e!r}); such steps "
+                      f"launch eagerly", flush=True)
+            try:
+                torch.cuda.synchronize()
+            except Exception:                    # noqa: BLE001
+                pass
+        self._last_logits = logits
+        return tokens, logits

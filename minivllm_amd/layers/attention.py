@@ -108,7 +108,8 @@ class Attention(nn.Module):
                 o = ops.paged_attention_prefill(q, self.k_cache, self.v_cache, ctx.cu_seqlens_q,
                                                 ctx.cu_seqlens_k, ctx.block_tables, self.scale,
                                                 ctx.max_seqlen_q, max_seqlen_k=ctx.max_seqlen_k,
-                                                total_k=ctx.total_k_tokens, q_rope=q_rope)
+                                                total_k=ctx.total_k_tokens, q_rope=q_rope,
+                                                work_items=ctx.prefill_items)
             else:
                 o = ops.flash_attention_prefill(q, k, v, ctx.cu_seqlens_q, self.scale,
                                                 ctx.max_seqlen_q, q_rope=q_rope)
@@ -134,7 +135,7 @@ class Attention(nn.Module):
                                         ctx.cu_seqlens_q[:Bp + 1], ctx.cu_seqlens_k[:Bp + 1],
                                         ctx.block_tables[:Bp], self.scale, ctx.max_seqlen_q,
                                         out=o[:Tp], max_seqlen_k=ctx.max_seqlen_k,
-                                        total_k=ctx.total_k_tokens)
+                                        total_k=ctx.total_k_tokens, work_items=ctx.prefill_items)
         ops.paged_attention_decode(q[Tp:Tp + Bd], self.k_cache, self.v_cache,
                                    ctx.block_tables[Bp:], ctx.context_lens, self.scale,
                                    ctx.max_context_len, out=o[Tp:Tp + Bd])

@@ -95,15 +95,17 @@ def _into(out, res):
 
 def paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k, block_tables, scale,
                             max_seqlen_q=None, out=None, max_seqlen_k=None, total_k=None,
-                            q_rope=None):
+                            q_rope=None, work_items=None):
     """``out``: optional [T, Hq, D] destination (a view into a larger buffer is fine).
     ``max_seqlen_k`` / ``total_k`` (longest context, sum of contexts) spare an fp8 cache's
-    widening pass a device synchronisation and an oversized scratch buffer."""
+    widening pass a device synchronisation and an oversized scratch buffer.  ``work_items``
+    (GPU): the step's work list, which makes the launch shape independent of the lengths
+    (``hip.prefill_work_items``)."""
     if _on_gpu(q):
         return _hip().paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k,
                                               block_tables, scale, max_seqlen_q, out=out,
                                               max_seqlen_k=max_seqlen_k, total_k=total_k,
-                                              q_rope=q_rope)
+                                              q_rope=q_rope, work_items=work_items)
     return _into(out, torch_ref.paged_attention_prefill(torch_ref.apply_q_rope(q, q_rope), k_cache,
                                                         v_cache, cu_seqlens_q, cu_seqlens_k,
                                                         block_tables, scale))

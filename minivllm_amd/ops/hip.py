@@ -59,7 +59,7 @@ _decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void,
 _prefill = _sig("mvl_flash_attention_prefill", _c_void, _c_long, _c_long, _c_void, _c_void,
                 _c_long, _c_long, _c_long, _c_void, _c_long, _c_long, _c_void, _c_void, _c_void,
                 _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-                _c_void, _c_void, _c_void, _c_float, _c_int, _c_void)
+                _c_void, _c_void, _c_void, _c_float, _c_int, _c_void, _c_int, _c_void)
 
 _naive = _sig("mvl_naive_attention", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long, _c_long,
               _c_void, _c_long, _c_long, _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -282,7 +282,7 @@ def flash_attention_prefill(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
     _check(_prefill(q.data_ptr(), qs_t, qs_h, k.data_ptr(), v.data_ptr(), ks_t, ks_h, 0,
                     out.data_ptr(), out.stride(0), out.stride(1), cu.data_ptr(), cu.data_ptr(),
                     None, 0, 1, scale, cu.numel() - 1, hq, hkv, d, max_seqlen, 0, _dt(q),
-                    pos.data_ptr() if pos is not None else None, cs, qw, eps, 0,
+                    pos.data_ptr() if pos is not None else None, cs, qw, eps, 0, None, 0,
                     _stream()), "flash_attention_prefill")
     return out
 
@@ -314,10 +314,13 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
                             max_seqlen_q: Optional[int] = None,
                             out: Optional[torch.Tensor] = None,
                             max_seqlen_k: Optional[int] = None,
-                            total_k: Optional[int] = None, q_rope=None) -> torch.Tensor:
+                            total_k: Optional[int] = None, q_rope=None,
+                            work_items: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Causal prefill through the block table (``q_len <= k_len`` per sequence).  An fp8 (e4m3)
     cache is read by the same kernel, which widens the tiles while staging them;
-    ``max_seqlen_k`` / ``total_k`` are accepted for callers that know them and not needed."""
+    ``max_seqlen_k`` / ``total_k`` are accepted for callers that know them and not needed.
+    ``work_items`` (int32, device; see ``prefill_work_items``): the launch then has one workgroup
+    per list slot and query head, independent of the lengths - the form a captured graph needs."""
     T, hq, d = q.shape
     hkv = k_cache.shape[2]
     cq, ck, bt = _i32(cu_seqlens_q), _i32(cu_seqlens_k), _i32(block_tables)
@@ -334,12 +337,51 @@ def paged_attention_prefill(q: torch.Tensor, k_cache: torch.Tensor, v_cache: tor
         out = torch.empty((T, hq, d), dtype=q.dtype, device=q.device)
     assert out.shape == (T, hq, d) and out.stride(2) == 1 and out.dtype == q.dtype
     pos, cs, qw, eps = _q_rope_args(q, q_rope)
+    if work_items is not None:
+        assert work_items.dtype == torch.int32 and work_items.is_contiguous() and work_items.is_cuda
+        if work_items.numel() == 0:
+            return out
+        max_seqlen_q = max(max_seqlen_q, 1)
     _check(_prefill(q.data_ptr(), qs_t, qs_h, k_cache.data_ptr(), v_cache.data_ptr(), st, sh, sb,
                     out.data_ptr(), out.stride(0), out.stride(1), cq.data_ptr(), ck.data_ptr(),
                     bt.data_ptr(), bt.stride(0), k_cache.shape[1], scale, cq.numel() - 1, hq, hkv,
                     d, max_seqlen_q, 1, _dt(q), pos.data_ptr() if pos is not None else None, cs, qw,
-                    eps, _kv_fp8(k_cache), _stream()), "paged_attention_prefill")
+                    eps, _kv_fp8(k_cache), work_items.data_ptr() if work_items is not None else None,
+                    work_items.numel() if work_items is not None else 0, _stream()),
+           "paged_attention_prefill")
     return out
+
+
+PREFILL_Q_TILE = 128          # query rows per tile of the prefill kernel (csrc/attn_prefill.hip)
+
+
+def prefill_work_items(q_lens, k_lens=None, slots: Optional[int] = None):
+    """The prefill kernel's work list for sequences with ``q_lens`` new tokens (numpy int array):
+    one entry ``sequence << 16 | pair`` per heavy / light pair of 128-row query tiles, long
+    contexts first, padded with -1 to ``slots`` entries.  Never more than
+    ``prefill_item_slots(sum(q_lens), len(q_lens))`` real entries."""
+    import numpy as np
+    q_lens = np.asarray(q_lens, dtype=np.int64)
+    n_qt = (q_lens + PREFILL_Q_TILE - 1) // PREFILL_Q_TILE
+    n_pairs = (n_qt + 1) // 2
+    order = np.argsort(-(np.asarray(k_lens, dtype=np.int64) if k_lens is not None else q_lens),
+                       kind="stable")
+    reps = n_pairs[order]
+    seq = np.repeat(order, reps)
+    first = np.cumsum(reps) - reps
+    pair = np.arange(int(reps.sum())) - np.repeat(first, reps)
+    items = ((seq << 16) | pair).astype(np.int32)
+    if slots is not None:
+        if items.size > slots:
+            raise ValueError(f"{items.size} work items do not fit {slots} slots")
+        items = np.concatenate([items, np.full(slots - items.size, -1, np.int32)])
+    return items
+
+
+def prefill_item_slots(num_tokens: int, num_seqs: int) -> int:
+    """Upper bound of the work-list length of any step with at most that many new tokens in at
+    most that many sequences (every sequence: ceil(ceil(n / 128) / 2) <= n / 256 + 1 pairs)."""
+    return num_tokens // (2 * PREFILL_Q_TILE) + num_seqs
 
 
 def decode_num_splits(batch: int, num_kv_heads: int, max_context_len: Optional[int]) -> int:

@@ -34,6 +34,9 @@ class Context:
     num_decode_seqs: int = 0
     num_prefill_tokens: int = 0
     total_k_tokens: int = 0                       # prefill: sum of context lengths (0 = unknown)
+    # GPU prefill: the attention kernel's work list (ops.hip.prefill_work_items), None = derive
+    # the launch from max_seqlen_q
+    prefill_items: Optional[torch.Tensor] = None
 
 
 _CONTEXT = Context()

@@ -242,3 +242,45 @@ def test_decode_logits_through_the_hand_written_gemm_kernels(gpu):
         hip._MID_CHOICE.clear()
         hip._MID_CHOICE.update(saved)
     g.exit(); c.exit()
+
+
+@pytest.mark.parametrize("num_seqs", [16, 64])
+def test_prefill_graphs_of_many_sequences_match_eager(gpu, num_seqs):
+    """A prefill step of 16 / 64 sequences replays a hipGraph too: the first step of a (token
+    bucket, sequence bucket) runs eagerly on the graph's static buffers and is recorded, later
+    steps of that shape replay it (other prompts, other lengths, cached prefixes).  Logits of
+    the recording step and of replays against the eager runner."""
+    kw = dict(max_num_sequences=64, max_num_batched_tokens=8192, max_cached_blocks=160)
+    e = _runner(_cfg("16q8kv", **kw))
+    g = _runner(_cfg("16q8kv", enforce_eager=False, graph_batch_sizes=[8], **kw), weights_from=e)
+    rng = np.random.default_rng(40 + num_seqs)
+    total = 4000 if num_seqs == 16 else 6000
+
+    def lengths():                       # num_seqs uneven lengths that add up to ``total``
+        while True:
+            cuts = np.sort(rng.choice(np.arange(1, total), size=num_seqs - 1, replace=False))
+            lens = np.diff(np.concatenate([[0], cuts, [total]])).tolist()
+            if max(lens) <= 1500:
+                return lens
+
+    rounds = [lengths() for _ in range(3)]
+    out = {}
+    for name, r in (("eager", e), ("graph", g)):
+        d = _Driver(r)
+        logs = []
+        for lens in rounds:
+            prompts = [np.random.default_rng(sum(lens[:i]) + n).integers(0, VOCAB, size=n).tolist()
+                       for i, n in enumerate(lens)]
+            seqs = d.seqs(prompts)
+            r.run(seqs, True)
+            logs.append(r._last_step_logits[:len(seqs)].float().cpu())
+            for s in seqs:
+                d.bm.deallocate(s)
+        out[name] = logs
+    keys = list(g.prefill_graphs)
+    assert any(k[1] >= num_seqs and k[0] >= total for k in keys), keys
+    assert g.prefill_graph_replays >= 2, g.prefill_graph_replays
+    errs = [_rel_err(a, b) for a, b in zip(out["graph"], out["eager"])]
+    print(f"[{num_seqs} sequences] prefill graph vs eager, relative logit error per step: {errs}")
+    assert max(errs) < REL_TOL_SAME, errs
+    e.exit(); g.exit()

@@ -1112,3 +1112,77 @@ def test_prefill_sweep_geometries(hip, dtype, hq, hkv):
         kc8, vc8 = kc.to(FP8), vc.to(FP8)
         want8 = ref.paged_attention_prefill(q_a, kc8.to(dtype), vc8.to(dtype), cu, ck, tables, scale)
         close(hip.paged_attention_prefill(q_a, kc8, vc8, cu, ck, tables, scale), want8, dtype)
+
+
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (16, 8, 64), (5, 1, 128)])
+@pytest.mark.parametrize("bs", [16, 256])
+def test_paged_prefill_from_a_work_list(hip, hq, hkv, d, bs):
+    """The launch form captured graphs use: one workgroup per (work-list slot, head), the list
+    (sequence << 16 | pair of query tiles, -1 = unused slot) in device memory.  Uneven lengths,
+    cached prefixes, zero-length sequence slots behind the real ones, far more slots than work,
+    the fused raw-Q transform; against the oracle and the length-derived launch (same bits:
+    the tiles and their arithmetic are the same, only who computes which pair differs)."""
+    torch.manual_seed(300 + hq)
+    dtype = torch.bfloat16
+    rng = torch.Generator().manual_seed(11)
+    B = 23
+    q_lens = [int(x) for x in torch.randint(1, 600, (B,), generator=rng)]
+    q_lens[2], q_lens[9], q_lens[20] = 1, 128, 257
+    prefix = [int(x) for x in torch.randint(0, 3, (B,), generator=rng) * 256]
+    k_lens = [a + b for a, b in zip(q_lens, prefix)]
+    scale, eps = 1.0 / math.sqrt(d), 1e-6
+    T = sum(q_lens)
+    kk = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    vv = torch.randn(sum(k_lens), hkv, d, device=DEV, dtype=dtype)
+    kc, vc, tables = _fill_paged(kk, vv, k_lens, bs, hkv, d, dtype)
+    q = torch.randn(T, hq, d, device=DEV, dtype=dtype)
+    # 9 unused sequence slots (zero length) as in a graph whose sequence bucket is 32
+    S = 32
+    cq = torch.tensor([0] + list(torch.tensor(q_lens).cumsum(0)) + [T] * (S - B), device=DEV, dtype=torch.int32)
+    ck = torch.tensor([0] + list(torch.tensor(k_lens).cumsum(0)) + [sum(k_lens)] * (S - B), device=DEV,
+                      dtype=torch.int32)
+    tab = torch.full((S, tables.shape[1]), -1, device=DEV, dtype=torch.int32)
+    tab[:B] = tables
+    slots = hip.prefill_item_slots(T + 100, S)
+    items_np = hip.prefill_work_items(q_lens, k_lens, slots=slots)
+    assert (items_np >= 0).sum() <= hip.prefill_item_slots(T, B)
+    items = torch.from_numpy(items_np).to(DEV)
+    want = ref.paged_attention_prefill(q, kc, vc, cq[:B + 1], ck[:B + 1], tables, scale)
+    plain = hip.paged_attention_prefill(q, kc, vc, cq[:B + 1], ck[:B + 1], tables, scale)
+    out = torch.full((T, hq, d), float("nan"), device=DEV, dtype=dtype)
+    hip.paged_attention_prefill(q, kc, vc, cq, ck, tab, scale, max_seqlen_q=T, out=out, work_items=items)
+    close(out, want, dtype)
+    assert torch.equal(out, plain)
+    # shuffled list: any order of the entries gives the same rows
+    perm = torch.randperm(slots)
+    out2 = torch.empty_like(out)
+    hip.paged_attention_prefill(q, kc, vc, cq, ck, tab, scale, max_seqlen_q=T, out=out2,
+                                work_items=items[perm.to(DEV)].contiguous())
+    assert torch.equal(out2, out)
+    # raw Q rows transformed on load
+    pos = torch.cat([torch.arange(p, p + n) for p, n in zip(prefix, q_lens)]).to(DEV, torch.int32)
+    cs = ref.build_cos_sin_cache(d, 2048, 10000.0, DEV)
+    qw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype)
+    rope = (pos, cs, qw, eps)
+    a = hip.paged_attention_prefill(q, kc, vc, cq[:B + 1], ck[:B + 1], tables, scale, q_rope=rope)
+    b = hip.paged_attention_prefill(q, kc, vc, cq, ck, tab, scale, max_seqlen_q=T, q_rope=rope,
+                                    work_items=items)
+    assert torch.equal(a, b)
+    close(b, ref.paged_attention_prefill(ref.apply_q_rope(q, rope), kc, vc, cq[:B + 1], ck[:B + 1],
+                                         tables, scale), dtype)
+    # captured once, replayed on other work
+    g = torch.cuda.CUDAGraph()
+    out3 = torch.empty_like(out)
+    with torch.cuda.graph(g):
+        hip.paged_attention_prefill(q, kc, vc, cq, ck, tab, scale, max_seqlen_q=T, out=out3, work_items=items)
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out3, out)
+    half = hip.prefill_work_items(q_lens[:10], k_lens[:10], slots=slots)
+    items.copy_(torch.from_numpy(half).to(DEV))
+    T10 = sum(q_lens[:10])
+    cq[11:] = T10
+    out3.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out3[:T10], out[:T10]) and not out3[T10:].any()
