@@ -224,6 +224,10 @@ class EngineConfig:
     car_timeout_ms: Optional[int] = None
     overlap_min_chunk_tokens: Optional[int] = None
     overlap_max_chunks: Optional[int] = None
+    # tensor parallelism: from this many rows on, a row-parallel output that feeds a norm is
+    # reduced as reduce-scatter -> norm on the rank's rows -> all-gather (parallel/group.py;
+    # None = 512, a huge value switches the route off)
+    scatter_norm_min_rows: Optional[int] = None
     # testing aid: with world_size 1 still create a (single-rank) process group and run every
     # tensor-parallel collective through it, graph capture included
     force_tp_group: bool = False

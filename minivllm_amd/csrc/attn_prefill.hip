@@ -112,24 +112,34 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     MVL_PROBE(0, wall_clock64());
 
     // ---- work decomposition: XCD-aware remap of the linear block id -----------------
-    int id = blockIdx.x;
-    {
+    const int G = a.Hq / a.Hkv;
+    int g, qti, kvh, b;
+    if (a.items != nullptr) {
+        // Work list: the real entries come first, the unused slots of the budget last, so the
+        // list is dealt to the XCDs in chunks of kItemChunk consecutive slots, round robin
+        // (blocks with equal id % 8 share an XCD): every XCD gets its share of the real work,
+        // the G heads of a (slot, KV head) and the neighbouring pairs of a sequence - which read
+        // the same K/V - stay on one L2.  n_items is a multiple of 8 kItemChunk (host).
+        constexpr int kItemChunk = 4;
+        const int xcd = blockIdx.x & 7;
+        int k = blockIdx.x >> 3;
+        g = k % G;                         k /= G;
+        const int within = k % kItemChunk; k /= kItemChunk;
+        const int chunk = k * 8 + xcd;                       // over (n_items / kItemChunk) x Hkv
+        kvh = chunk % a.Hkv;
+        const int slot = (chunk / a.Hkv) * kItemChunk + within;
+        const int it = a.items[slot];
+        if (it < 0) return;                                  // a slot of the budget this step does not use
+        b = it >> 16;
+        qti = it & 0xffff;
+    } else {
+        int id = blockIdx.x;
         const int n = a.total_wg;
         const int q8 = n >> 3, r8 = n & 7, x = id & 7;
         // blocks with equal (id % 8) share an XCD: give each XCD a contiguous range
         id = (x < r8 ? x * (q8 + 1) : r8 * (q8 + 1) + (x - r8) * q8) + (id >> 3);
-    }
-    const int G = a.Hq / a.Hkv;
-    const int g = id % G;              id /= G;
-    int qti = id % a.n_items;          id /= a.n_items;
-    int kvh, b;
-    if (a.items != nullptr) {
-        kvh = id;                                        // grid = G x n_items x Hkv
-        const int it = a.items[qti];
-        if (it < 0) return;                              // a slot of the budget this step does not use
-        b = it >> 16;
-        qti = it & 0xffff;
-    } else {
+        g = id % G;                id /= G;
+        qti = id % a.n_items;      id /= a.n_items;
         kvh = id % a.Hkv;
         b = id / a.Hkv;
     }
@@ -649,7 +659,8 @@ extern "C" int mvl_flash_attention_prefill(
         const int* positions, const float* cos_sin, const void* q_w, float eps, int kv_fp8,
         const int* items, int n_item_slots, void* stream) {
     if (B == 0 || max_q_len <= 0) return 0;
-    if (items != nullptr && (n_item_slots <= 0 || B > 32767)) return items != nullptr && n_item_slots == 0 ? 0 : -1;
+    if (items != nullptr && n_item_slots == 0) return 0;
+    if (items != nullptr && (n_item_slots < 0 || n_item_slots % 32 != 0 || B > 32767)) return -1;
     if ((D != 64 && D != 128) || Hq % Hkv != 0) return -1;
     if (paged && (block_size & (block_size - 1))) return -1;
     if (kv_fp8 && !paged) return -1;

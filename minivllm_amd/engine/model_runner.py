@@ -141,6 +141,7 @@ class ModelRunner:
                 and (cfg.custom_all_reduce or os.environ.get("MINIVLLM_CUSTOM_AR") == "1")):
             pg.enable_custom_all_reduce(self.device, one_shot_max_bytes=cfg.car_one_shot_max_bytes,
                                         timeout_ms=cfg.car_timeout_ms)
+        pg.configure_scatter_norm(cfg.scatter_norm_min_rows)
         if cfg.overlap_min_chunk_tokens or cfg.overlap_max_chunks:
             from minivllm_amd.parallel import overlap
             overlap.configure(cfg.overlap_min_chunk_tokens, cfg.overlap_max_chunks)
@@ -1307,6 +1308,9 @@ class ModelRunner:
             if self.rank == 0:
                 print(f"[runner] prefill graph {key} could not be captured ({e!r}); such steps "
                       f"launch eagerly", flush=True)
+                if os.environ.get("MINIVLLM_DEBUG_CAPTURE") == "1":
+                    import traceback
+                    traceback.print_exc()
             try:
                 torch.cuda.synchronize()
             except Exception:                    # noqa: BLE001

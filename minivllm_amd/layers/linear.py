@@ -154,14 +154,19 @@ class RowParallelLinear(LinearBase):
         """``defer_reduce``: the caller hands the result to ``ops.norm_linear`` / ``RMSNorm``
         with a residual and to nothing else.  Under the peer-to-peer all-reduce the partial sum
         of a decode-sized output is then returned as ``ops.PendingReduce`` and that consumer
-        reduces, adds and normalises in one kernel.  The same flag lets a K-split decode GEMM
+        reduces, adds and normalises in one kernel; a prefill-sized output leaves as a
+        reduce-scatter (chunk-pipelined against the GEMM) and the consumer norms this rank's rows
+        only before gathering them (``pg.can_defer_reduce``).  The same flag lets a K-split decode GEMM
         hand its unsummed slices (``ops.SplitKPartials``) on: to the norm on a single rank, to
         the reducing kernel (which sums them while staging) otherwise."""
         bias = self.bias if self.tp_rank == 0 else None
         if (self.tp_size > 1 or pg.collectives_active()) and self.reduce_results:
-            if defer_reduce and x.dim() == 2 and pg.can_defer_reduce(
-                    x.shape[0], self.weight.shape[0], x.dtype, x.is_cuda):
+            from minivllm_amd.parallel.overlap import row_parallel_linear, row_parallel_linear_scatter
+            how = pg.can_defer_reduce(x.shape[0], self.weight.shape[0], x.dtype, x.is_cuda) \
+                if defer_reduce and x.dim() == 2 else ""
+            if how == "p2p":
                 return ops.PendingReduce(ops.linear(x, self.weight, bias, to_norm=bias is None))
-            from minivllm_amd.parallel.overlap import row_parallel_linear
+            if how == "scatter":         # prefill-sized: the sum leaves as a reduce-scatter
+                return ops.PendingReduce(scattered=row_parallel_linear_scatter(x, self.weight, bias))
             return row_parallel_linear(x, self.weight, bias)
         return ops.linear(x, self.weight, bias, to_norm=defer_reduce and x.dim() == 2)

@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from . import torch_ref
-from .partials import PendingReduce, ResidualShard, SplitKPartials
+from .partials import PendingReduce, ResidualShard, ScatteredRows, SplitKPartials
 
 
 def _hip():

@@ -358,7 +358,8 @@ PREFILL_Q_TILE = 128          # query rows per tile of the prefill kernel (csrc/
 def prefill_work_items(q_lens, k_lens=None, slots: Optional[int] = None):
     """The prefill kernel's work list for sequences with ``q_lens`` new tokens (numpy int array):
     one entry ``sequence << 16 | pair`` per heavy / light pair of 128-row query tiles, long
-    contexts first, padded with -1 to ``slots`` entries.  Never more than
+    contexts first, padded with -1 to ``slots`` entries (default: the next multiple of 32, the
+    granularity the kernel deals the list out in).  Never more than
     ``prefill_item_slots(sum(q_lens), len(q_lens))`` real entries."""
     import numpy as np
     q_lens = np.asarray(q_lens, dtype=np.int64)
@@ -371,17 +372,18 @@ def prefill_work_items(q_lens, k_lens=None, slots: Optional[int] = None):
     first = np.cumsum(reps) - reps
     pair = np.arange(int(reps.sum())) - np.repeat(first, reps)
     items = ((seq << 16) | pair).astype(np.int32)
-    if slots is not None:
-        if items.size > slots:
-            raise ValueError(f"{items.size} work items do not fit {slots} slots")
-        items = np.concatenate([items, np.full(slots - items.size, -1, np.int32)])
-    return items
+    if slots is None:
+        slots = (items.size + 31) // 32 * 32
+    if items.size > slots or slots % 32:
+        raise ValueError(f"{items.size} work items do not fit {slots} slots (a multiple of 32)")
+    return np.concatenate([items, np.full(slots - items.size, -1, np.int32)])
 
 
 def prefill_item_slots(num_tokens: int, num_seqs: int) -> int:
     """Upper bound of the work-list length of any step with at most that many new tokens in at
     most that many sequences (every sequence: ceil(ceil(n / 128) / 2) <= n / 256 + 1 pairs)."""
-    return num_tokens // (2 * PREFILL_Q_TILE) + num_seqs
+    n = num_tokens // (2 * PREFILL_Q_TILE) + num_seqs
+    return (n + 31) // 32 * 32           # the kernel deals the list to the 8 XCDs in chunks of 4
 
 
 def decode_num_splits(batch: int, num_kv_heads: int, max_context_len: Optional[int]) -> int:

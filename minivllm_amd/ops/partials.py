@@ -9,9 +9,11 @@ That lets the work between the GEMM's accumulators and the normalised row be rea
 * ``PendingReduce``  - this rank's partial sum of a row-parallel projection (a tensor or
   ``SplitKPartials``) whose all-reduce over the TP group is left to the consumer, which runs
   reduce + residual add + norm as one peer-to-peer kernel when it can.
-* ``ResidualShard``  - this rank's rows of the residual stream after a two-shot fused
-  reduce + norm: rank r keeps rows [r R, (r + 1) R) (R = rows / tp) and only normalised rows
-  are gathered, so the stream stays row-sharded until the next fused norm consumes it.
+* ``ResidualShard``  - this rank's rows of the residual stream after a reduce-scatter shaped
+  reduce + norm (the two-shot peer-to-peer kernel for decode-sized batches; RCCL reduce-scatter,
+  norm on the rank's rows, all-gather for prefill-sized ones): only normalised rows are
+  gathered, so the stream stays row-sharded until the next such norm consumes it and the norm
+  itself costs 1 / tp of a replicated one.
 
 They are real types, not attributes hung on tensors: a ``view`` / ``reshape`` / arithmetic on
 one of them raises instead of silently dropping the pending work.  Only ``ops.rms_norm``,
@@ -59,32 +61,55 @@ class SplitKPartials:
         return hip.splitk_add_rms_norm(self, residual, weight, eps)
 
 
+class ScatteredRows:
+    """A row-parallel projection whose partial sums are being reduce-SCATTERED: ``own`` holds this
+    rank's rows of the sum ([total_rows / tp, hidden]; for every token chunk ``bounds[i] ..
+    bounds[i + 1]`` the rank owns an equal share, in rank order, and ``own`` concatenates the
+    shares chunk by chunk), ``works`` the collectives still in flight (None entries: done),
+    ``keep`` whatever must outlive them."""
+
+    __slots__ = ("own", "works", "bounds", "total_rows", "keep")
+
+    def __init__(self, own: torch.Tensor, works, bounds, total_rows: int, keep=None):
+        self.own, self.works, self.bounds, self.total_rows, self.keep = own, works, tuple(bounds), total_rows, keep
+
+    def wait(self) -> None:
+        for w in self.works:
+            if w is not None:
+                w.wait()
+        self.works, self.keep = [], None
+
+
 class PendingReduce:
-    """A row-parallel partial sum [rows, hidden] whose all-reduce is still to be done."""
+    """A row-parallel partial sum [rows, hidden] whose reduction over the TP group is still to be
+    finished by its consumer: ``value`` (tensor or ``SplitKPartials``) when nothing has been
+    sent yet, ``scattered`` when the sum is already on its way as a reduce-scatter."""
 
-    __slots__ = ("value",)
+    __slots__ = ("value", "scattered")
 
-    def __init__(self, value: Union[torch.Tensor, SplitKPartials]):
-        assert torch.is_tensor(value) or isinstance(value, SplitKPartials)
-        self.value = value
+    def __init__(self, value: Union[torch.Tensor, SplitKPartials, None] = None,
+                 scattered: Optional[ScatteredRows] = None):
+        assert (value is None) != (scattered is None)
+        assert value is None or torch.is_tensor(value) or isinstance(value, SplitKPartials)
+        self.value, self.scattered = value, scattered
 
     @property
     def shape(self):
+        if self.scattered is not None:
+            return (self.scattered.total_rows, self.scattered.own.shape[1])
         return self.value.shape
-
-    def local_tensor(self) -> torch.Tensor:
-        """This rank's partial sum as a plain tensor (K slices summed)."""
-        v = self.value
-        return v.materialize() if isinstance(v, SplitKPartials) else v
 
 
 class ResidualShard:
-    """``rows``: this rank's [total_rows / tp, hidden] slice of the residual stream."""
+    """``rows``: this rank's [total_rows / tp, hidden] share of the residual stream.  ``bounds``
+    None: the share is rows [rank R, (rank + 1) R); a tuple of chunk bounds: an equal share of
+    every chunk (see ``ScatteredRows``).  Producer and consumer must agree on it, which they do
+    within a step: every layer sees the same row count and plans the same chunks."""
 
-    __slots__ = ("rows", "total_rows")
+    __slots__ = ("rows", "total_rows", "bounds")
 
-    def __init__(self, rows: torch.Tensor, total_rows: int):
-        self.rows, self.total_rows = rows, total_rows
+    def __init__(self, rows: torch.Tensor, total_rows: int, bounds=None):
+        self.rows, self.total_rows, self.bounds = rows, total_rows, (None if bounds is None else tuple(bounds))
 
 
 def is_plain(x) -> bool:

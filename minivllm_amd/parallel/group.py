@@ -194,26 +194,117 @@ def tp_all_reduce(x: torch.Tensor) -> torch.Tensor:
     return x
 
 
-def can_defer_reduce(rows: int, hidden: int, dtype: torch.dtype, on_gpu: bool) -> bool:
-    """True when the all-reduce of a [rows, hidden] row-parallel partial sum may be left to the
-    (residual add + RMSNorm) that consumes it: the peer-to-peer kernel is active and the message
-    fits its buffers.  Whether that consumer really runs one fused kernel (one-shot up to a few
-    hundred KB, two-shot with a row-sharded residual above, neither for odd shapes) is decided
-    there, on the operands; every case ends in the same values."""
-    if _CUSTOM_AR is None or not on_gpu or dtype not in (torch.bfloat16, torch.float16):
-        return False
-    n = rows * hidden
-    return 0 < n * 2 <= _CUSTOM_AR.max_bytes and hidden % 8 == 0
+# From this many rows on a row-parallel output that feeds (residual add +) RMSNorm is reduced as
+# reduce-scatter -> add + norm on the rank's own rows -> all-gather of the normalised rows
+# instead of all-reduce -> add + norm on every row on every rank: the same bytes on the links,
+# 1 / tp of the norm's HBM passes (at 16384 x 4096 the replicated norms are 5.5 ms of a 30 ms
+# Qwen3-8B TP=8 prefill step per rank), and the residual stream is never sent at all.
+SP_MIN_ROWS = int(os.environ.get("MINIVLLM_SP_MIN_ROWS", 512))
+SCATTER_NORM_CALLS = 0          # how often this process took that route (tests, bench JSON)
+
+
+def configure_scatter_norm(min_rows: Optional[int]) -> None:
+    global SP_MIN_ROWS
+    if min_rows is not None:
+        SP_MIN_ROWS = int(min_rows)
+
+
+def scatter_norm_ok(rows: int) -> bool:
+    return _TP_GROUP is not None and rows >= SP_MIN_ROWS and rows % _TP_SIZE == 0
+
+
+def can_defer_reduce(rows: int, hidden: int, dtype: torch.dtype, on_gpu: bool) -> str:
+    """How the all-reduce of a [rows, hidden] row-parallel partial sum may be left to the
+    (residual add + RMSNorm) that consumes it: ``"p2p"`` (the peer-to-peer kernels are active
+    and the message fits their buffers: the consumer runs reduce + add + norm as one kernel when
+    the operands allow), ``"scatter"`` (prefill-sized: reduce-scatter, norm on own rows,
+    all-gather) or ``""`` (all-reduce now).  Every case ends in the same values."""
+    if _TP_GROUP is None:
+        return ""
+    if (_CUSTOM_AR is not None and on_gpu and dtype in (torch.bfloat16, torch.float16)
+            and 0 < rows * hidden * 2 <= _CUSTOM_AR.max_bytes and hidden % 8 == 0):
+        return "p2p"
+    return "scatter" if scatter_norm_ok(rows) else ""
+
+
+def reduce_scatter_rows(out: torch.Tensor, inp: torch.Tensor, async_op: bool = False):
+    """``out`` [rows / tp, hidden] <- this rank's share (rank order) of the sum over ranks of
+    ``inp`` [rows, hidden].  Returns the collective's work handle when ``async_op`` (else None)."""
+    per = inp.shape[0] // _TP_SIZE
+    mine = slice(_TP_RANK * per, (_TP_RANK + 1) * per)
+    if _REHEARSAL:                                    # nobody to add: this rank's own rows
+        out.copy_(inp[mine])
+        return None
+    if (_HOST_STAGED and inp.is_cuda) or dist.get_backend(_TP_GROUP) == "gloo":
+        h = inp.cpu() if inp.is_cuda else inp.clone()          # gloo has no reduce-scatter
+        dist.all_reduce(h, group=_TP_GROUP)
+        out.copy_(h[mine])
+        return None
+    w = dist.reduce_scatter_tensor(out, inp, group=_TP_GROUP, async_op=async_op)
+    return w if async_op else None
+
+
+def all_gather_rows(out: torch.Tensor, inp: torch.Tensor) -> None:
+    """``out`` [rows, hidden] <- every rank's ``inp`` [rows / tp, hidden], in rank order."""
+    per = inp.shape[0]
+    if _REHEARSAL:                                    # the absent peers' rows: copies of this rank's
+        out.view(_TP_SIZE, per, -1).copy_(inp.unsqueeze(0).expand(_TP_SIZE, per, inp.shape[1]))
+        return
+    if (_HOST_STAGED and inp.is_cuda) or dist.get_backend(_TP_GROUP) == "gloo":
+        parts = _all_gather_parts(inp)
+        for r, p in enumerate(parts):
+            out[r * per:(r + 1) * per].copy_(p)
+        return
+    dist.all_gather_into_tensor(out, inp.contiguous(), group=_TP_GROUP)
+
+
+def _finish_scattered(sc, residual, gamma: torch.Tensor, eps: float):
+    """Second half of reduce-scatter -> norm -> all-gather: ``sc.own`` holds (or is about to
+    hold) this rank's rows of the sum."""
+    from .. import ops
+    from ..ops.partials import ResidualShard
+    global SCATTER_NORM_CALLS
+    SCATTER_NORM_CALLS += 1
+    sc.wait()
+    own, bounds, T = sc.own, sc.bounds, sc.total_rows
+    chunks = list(zip(bounds[:-1], bounds[1:]))
+
+    def my_rows(lo, hi):
+        per = (hi - lo) // _TP_SIZE
+        return lo + _TP_RANK * per, lo + (_TP_RANK + 1) * per
+    if residual is None:
+        h_rows, res_rows = ops.rms_norm(own, gamma, eps), own
+    else:
+        if isinstance(residual, ResidualShard):
+            if residual.total_rows != T or residual.bounds != bounds:
+                raise RuntimeError("row-sharded residual and scattered projection disagree on who "
+                                   "owns which rows")
+            res_rows = residual.rows
+        else:                                         # whole stream (first norm of a step): my rows
+            res_rows = torch.cat([residual[slice(*my_rows(lo, hi))] for lo, hi in chunks]) \
+                if len(chunks) > 1 else residual[slice(*my_rows(*chunks[0]))]
+        h_rows, res_rows = ops.add_rms_norm(own, res_rows, gamma, eps)
+    h = torch.empty((T, own.shape[1]), dtype=own.dtype, device=own.device)
+    off = 0
+    for lo, hi in chunks:
+        per = (hi - lo) // _TP_SIZE
+        all_gather_rows(h[lo:hi], h_rows[off:off + per])
+        off += per
+    return h, ResidualShard(res_rows, T, bounds)
 
 
 def tp_reduce_add_rms_norm(x, residual, gamma: torch.Tensor, eps: float):
     """Consumer of a ``PendingReduce``: ``(rms_norm(all_reduce(x) + residual) * gamma,
-    all_reduce(x) + residual)``, as one peer-to-peer kernel when the operands allow it and as
-    all-reduce + fused add/norm otherwise.  The second value is a ``ResidualShard`` when the
-    two-shot fused kernel ran (and ``residual`` may be one from an earlier such call)."""
+    all_reduce(x) + residual)``.  Decode-sized, peer-to-peer kernels active: one kernel when the
+    operands allow it.  Prefill-sized: the producer has reduce-scattered the rows; norm on this
+    rank's rows, all-gather of the normalised rows.  Otherwise all-reduce + fused add/norm.  The
+    second value is a ``ResidualShard`` in the reduce-scatter shaped cases (and ``residual`` may
+    be one from an earlier such call)."""
     from .. import ops
     from ..ops.partials import PendingReduce, ResidualShard, SplitKPartials
     assert isinstance(x, PendingReduce)
+    if x.scattered is not None:
+        return _finish_scattered(x.scattered, residual, gamma, eps)
     val = x.value
     if residual is not None and _CUSTOM_AR is not None:
         mode = _CUSTOM_AR.norm_mode(val, residual, gamma)

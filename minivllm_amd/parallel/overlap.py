@@ -82,3 +82,29 @@ def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
     for w in works:
         w.wait()              # makes the compute stream wait for the collective's event
     return out
+
+
+def row_parallel_linear_scatter(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                                num_chunks: Optional[int] = None):
+    """``x @ weight.T (+ bias)`` summed over the TP group and left SCATTERED: every rank ends up
+    with its share of the rows (``ops.ScatteredRows``), for a consumer that works row-wise
+    (residual add + RMSNorm) and gathers afterwards.  Chunk i is reduce-scattered while the GEMM
+    of chunk i + 1 runs; the collectives are still in flight when this returns.  Each GEMM goes
+    through ``ops.linear`` (the hand-written prefill kernel where it was measured faster)."""
+    from ..ops.partials import ScatteredRows
+    P = pg.tp_size()
+    T, H = x.shape[0], weight.shape[0]
+    n = plan_chunks(T) if num_chunks is None else num_chunks
+    bounds = chunk_bounds(T, n) if n > 1 else [0, T]
+    if any((hi - lo) % P for lo, hi in zip(bounds[:-1], bounds[1:])):
+        bounds = [0, T]                               # a chunk the ranks cannot share evenly
+    pipelined = len(bounds) > 2 and not pg.host_staged_collectives()
+    own = torch.empty((T // P, H), dtype=x.dtype, device=x.device)
+    works, keep, off = [], [], 0
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        y = ops.linear(x[lo:hi], weight, bias)
+        per = (hi - lo) // P
+        works.append(pg.reduce_scatter_rows(own[off:off + per], y, async_op=pipelined))
+        keep.append(y)
+        off += per
+    return ScatteredRows(own, works, bounds, T, keep)

@@ -251,8 +251,12 @@ def test_prefill_graphs_of_many_sequences_match_eager(gpu, num_seqs):
     steps of that shape replay it (other prompts, other lengths, cached prefixes).  Logits of
     the recording step and of replays against the eager runner."""
     kw = dict(max_num_sequences=64, max_num_batched_tokens=8192, max_cached_blocks=160)
-    e = _runner(_cfg("16q8kv", **kw))
-    g = _runner(_cfg("16q8kv", enforce_eager=False, graph_batch_sizes=[8], **kw), weights_from=e)
+    # no logit spy here: it copies to the host inside ``_sample``, which a capture cannot record
+    # (the runner would mark the shape as eager-only); ``_last_step_logits`` is read instead
+    from minivllm_amd.engine.model_runner import ModelRunner
+    e = ModelRunner(_cfg("16q8kv", **kw), 0)
+    g = ModelRunner(_cfg("16q8kv", enforce_eager=False, graph_batch_sizes=[8], **kw), 0)
+    g.model.load_state_dict(e.model.state_dict())
     rng = np.random.default_rng(40 + num_seqs)
     total = 4000 if num_seqs == 16 else 6000
 

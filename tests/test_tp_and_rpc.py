@@ -386,3 +386,39 @@ def test_shard_rehearsal_builds_one_ranks_shapes_and_runs():
     assert not pg.is_rehearsal() and pg.tp_size() == 1
     with pytest.raises(ValueError):
         dataclasses.replace(_cfg(2, port), tp_shard=2).validate()
+
+
+@pytest.mark.parametrize("world,chunks", [(2, None), (4, 2)])
+def test_prefill_reduce_scatter_norm_all_gather_matches_tp1(world, chunks):
+    """Prefill-sized row-parallel outputs are reduce-scattered, normalised on the rank's own rows
+    (row-sharded residual stream) and the normalised rows all-gathered; with ``chunks`` the GEMM
+    is split over token chunks and each rank owns a share of every chunk.  Greedy tokens must
+    equal one rank's (fp32 on the CPU: the sums are exact enough)."""
+    import dataclasses
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    from minivllm_amd.parallel import group as pg
+    port = 28800 + os.getpid() % 250 + 3 * world
+
+    def run(w, p):
+        base = _cfg(w, p)
+        cfg = dataclasses.replace(
+            base, scatter_norm_min_rows=8, overlap_max_chunks=chunks,
+            overlap_min_chunk_tokens=64 if chunks else None, max_num_batched_tokens=256,
+            max_cached_blocks=64,
+            model=dataclasses.replace(base.model, num_kv_heads=4, intermediate_size=128))
+        eng = LLMEngine(cfg)
+        rng = np.random.default_rng(6)
+        # 256 rows in one step: two chunks of 128 when chunking is on
+        lens = (64, 70, 60, 62) if chunks else (12, 20, 9, 23)
+        prompts = [rng.integers(0, 331, size=n).tolist() for n in lens]
+        before = pg.SCATTER_NORM_CALLS
+        out = eng.generate(prompts, SamplingParams(temperature=0, max_tokens=6, ignore_eos=True))
+        used = pg.SCATTER_NORM_CALLS - before
+        eng.exit()
+        pg.configure_scatter_norm(512)
+        return out["token_ids"], used
+
+    many, used = run(world, port)
+    one, used1 = run(1, port + 1)
+    assert used >= 4 and used1 == 0, (used, used1)        # 2 layers: o, down, o, down (into the final norm)
+    assert many == one
