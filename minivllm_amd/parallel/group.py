@@ -26,6 +26,12 @@ _TP_GROUP: Optional[dist.ProcessGroup] = None
 # one rank's compute, launches and collective entry/exit: the floor under that rank's step time
 # on a real node.  Outputs are not the model's (partial sums are never completed).
 _REHEARSAL = False
+# What a rehearsed collective does locally.  "compute" (default): only what the data flow needs
+# (a reduce-scatter keeps this rank's rows, an all-gather fills this rank's slice): the step is
+# then one rank's compute and launches, nothing else.  "traffic": an all-gather also writes the
+# absent peers' slices (copies of this rank's), i.e. the local memory writes of the real
+# collective are paid as well.  MINIVLLM_REHEARSAL_COLLECTIVES.
+_REHEARSAL_TRAFFIC = os.environ.get("MINIVLLM_REHEARSAL_COLLECTIVES", "compute") == "traffic"
 _OWNS_DEFAULT_GROUP = False
 # gloo has no device transport: with GPU tensors (several ranks sharing one device, used only to
 # rehearse the TP control flow on a single-GPU machine) every collective is staged through host
@@ -247,8 +253,11 @@ def reduce_scatter_rows(out: torch.Tensor, inp: torch.Tensor, async_op: bool = F
 def all_gather_rows(out: torch.Tensor, inp: torch.Tensor) -> None:
     """``out`` [rows, hidden] <- every rank's ``inp`` [rows / tp, hidden], in rank order."""
     per = inp.shape[0]
-    if _REHEARSAL:                                    # the absent peers' rows: copies of this rank's
-        out.view(_TP_SIZE, per, -1).copy_(inp.unsqueeze(0).expand(_TP_SIZE, per, inp.shape[1]))
+    if _REHEARSAL:
+        if _REHEARSAL_TRAFFIC:                        # the absent peers' rows: copies of this rank's
+            out.view(_TP_SIZE, per, -1).copy_(inp.unsqueeze(0).expand(_TP_SIZE, per, inp.shape[1]))
+        else:
+            out[_TP_RANK * per:(_TP_RANK + 1) * per].copy_(inp)
         return
     if (_HOST_STAGED and inp.is_cuda) or dist.get_backend(_TP_GROUP) == "gloo":
         parts = _all_gather_parts(inp)
