@@ -88,7 +88,8 @@ def benchmark_decode_at_scale(config_name, context_lengths, batch_sizes, block_s
 
 def main():
     ap = argparse.ArgumentParser(description="Large Model Attention Benchmark")
-    ap.add_argument("--config", default="qwen3-8b", choices=list(MODEL_CONFIGS))
+    ap.add_argument("--config", default="qwen3-8b", choices=list(MODEL_CONFIGS) + ["all"],
+                    help="head geometry to sweep ('all': every configuration of the table in turn)")
     ap.add_argument("--mode", default="all", choices=["prefill", "decode", "all"])
     ap.add_argument("--quick", action="store_true", help="fewer configurations")
     ap.add_argument("--json", default=None)
@@ -106,10 +107,14 @@ def main():
         seqs, batches = [512, 1024, 2048, 4096, 8192], [1, 2, 4, 8, 16]
         ctxs = [512, 1024, 2048, 4096, 8192, 16384]
     res = {}
-    if args.mode in ("prefill", "all"):
-        res["prefill"] = benchmark_prefill_at_scale(args.config, seqs, batches)
-    if args.mode in ("decode", "all"):
-        res["decode"] = benchmark_decode_at_scale(args.config, ctxs, batches)
+    for config in (list(MODEL_CONFIGS) if args.config == "all" else [args.config]):
+        r = res.setdefault(config, {})
+        if args.mode in ("prefill", "all"):
+            r["prefill"] = benchmark_prefill_at_scale(config, seqs, batches)
+        if args.mode in ("decode", "all"):
+            r["decode"] = benchmark_decode_at_scale(config, ctxs, batches)
+    if args.config != "all":
+        res = res[args.config]
     print("\n" + "=" * 70 + "\nBenchmark Complete\n" + "=" * 70)
     if args.json:
         Path(args.json).write_text(json.dumps(res, indent=1))

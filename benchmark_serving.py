@@ -56,6 +56,11 @@ def main():
                     help="cap the KV blocks per engine (replicas sharing one GPU: equal shares)")
     ap.add_argument("--device", default="cuda")
     ap.add_argument("--eager", action="store_true")
+    ap.add_argument("--warmup-requests", type=int, default=0,
+                    help="requests served (at the same rate and lengths) before the measured ones: "
+                         "step shapes seen for the first time capture their hipGraphs here")
+    ap.add_argument("--no-lazy-prefill-graphs", action="store_true",
+                    help="prefill steps beyond the start-up graphs launch eagerly (A/B)")
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--json", default=None)
     a = ap.parse_args()
@@ -81,7 +86,8 @@ def main():
                        max_model_length=int(in_lens.max() + out_lens.max()) + 8,
                        dtype=torch.bfloat16 if on_gpu else torch.float32, device=a.device,
                        gpu_memory_utilization=a.gpu_memory_utilization,
-                       max_cached_blocks=a.kv_blocks, seed=a.seed)
+                       max_cached_blocks=a.kv_blocks, seed=a.seed,
+                       prefill_graph_lazy=not a.no_lazy_prefill_graphs)
     if a.data_parallel_size > 1:
         from minivllm_amd.serve import DataParallelAsyncEngine
         eng = DataParallelAsyncEngine(cfg, a.data_parallel_size)
@@ -89,6 +95,20 @@ def main():
         eng = AsyncLLMEngine(cfg)
     # one request through the whole path before the clock starts
     eng.generate(prompts[0][:16], SamplingParams(temperature=0.8, max_tokens=4, ignore_eos=True))
+
+    if a.warmup_requests:
+        wrng = np.random.default_rng(a.seed + 1)
+        warm, tw = [], time.perf_counter()
+        gaps = wrng.exponential(1.0 / a.rate, a.warmup_requests).cumsum() if a.rate > 0 else np.zeros(a.warmup_requests)
+        for i in range(a.warmup_requests):
+            wait = tw + gaps[i] - time.perf_counter()
+            if wait > 0:
+                time.sleep(wait)
+            j = int(wrng.integers(0, a.requests))
+            warm.append(eng.submit(prompts[j], SamplingParams(temperature=0.8, max_tokens=int(out_lens[j]),
+                                                              ignore_eos=True)))
+        for h in warm:
+            h.result(timeout=1800)
 
     t0 = time.perf_counter()
     handles = []
@@ -117,6 +137,8 @@ def main():
            "ttft_ms": pct(ttft), "tpot_ms": pct(tpot), "e2e_ms": pct(e2e),
            "prefill_steps": st["prefill_steps"], "decode_steps": st["decode_steps"],
            "preemptions": st["preemptions"],
+           "prefill_graphs": st.get("prefill_graphs"), "prefill_graph_replays": st.get("prefill_graph_replays"),
+           "warmup_requests": a.warmup_requests,
            "kv_blocks": st["kv_blocks"], "kv_blocks_free_at_end": st["kv_blocks_free"],
            "config": {"kv_cache_dtype": a.kv_cache_dtype, "input_len": a.input_len, "output_len": a.output_len, "jitter": a.jitter,
                       "data_parallel_size": a.data_parallel_size,

@@ -215,7 +215,9 @@ class AsyncLLMEngine:
                    preemptions=sch.num_preemptions,
                    kv_blocks_free=sch.block_manager.num_free_blocks,
                    kv_blocks=sch.block_manager.num_blocks,
-                   prefix_hits=sch.block_manager.num_prefix_hits)
+                   prefix_hits=sch.block_manager.num_prefix_hits,
+                   prefill_graphs=len(eng.model_runner.prefill_graphs),
+                   prefill_graph_replays=eng.model_runner.prefill_graph_replays)
         self._stats_snapshot = out                         # one reference assignment
 
     # ------------------------------------------------------- engine thread
