@@ -182,12 +182,14 @@ class EngineConfig:
     # ~/.cache/minivllm_amd/gemm_choices.json (env MINIVLLM_GEMM_CHOICES overrides), "" = off.
     # Under tensor parallelism rank 0's table is what every rank uses.
     gemm_choice_cache: str = "auto"
-    # GPU only, experimental: multiply each layer norm's scale vector into the weights of the
-    # projection behind it at load time, which lets 1-2 row decode batches run (residual add +
-    # norm + projection) as one kernel (csrc/skinny_norm_gemm.hip).  Measured on Qwen3-8B: 3.93
-    # vs 3.95 ms per step at batch 1 and slower from 8 rows up (the fused kernel reads x and the
-    # residual as MFMA fragments), so it is off by default.
-    fold_norm_weights: bool = False
+    # GPU: multiply each layer norm's scale vector into the weights of the projection behind it
+    # at load time (same math).  The normalisation left in front of that projection is then a
+    # per-row factor, which (a) the prefill GEMM applies in its epilogue from row sums of squares
+    # that the preceding o / down GEMM accumulated while adding the residual stream
+    # (csrc/big_gemm.hip: no norm passes over [T, hidden] in a prefill layer) and (b) lets 1-2 row
+    # decode batches run (residual add + norm + projection) as one kernel
+    # (csrc/skinny_norm_gemm.hip).  None = on for single-rank GPU engines.
+    fold_norm_weights: Optional[bool] = None
     # let a prompt longer than the step's token budget be prefetched over several steps (the
     # reference can never schedule such a prompt)
     enable_chunked_prefill: bool = True

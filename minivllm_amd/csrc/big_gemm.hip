@@ -34,6 +34,16 @@
 //    one, and the stores of a finished tile drain under the next tile's MFMAs (rows beyond M
 //    are dropped by the range check of the buffer stores).
 //
+// Two optional epilogue duties take the (residual add + RMSNorm) passes out of a prefill layer
+// (reference: src/myvllm/layers/layernorm.py:19-22, src/myvllm/models/qwen3.py:191-195,216):
+//  * RES (o / down projections): out is the residual stream, updated in place,
+//    r = round(acc + bias + residual), and the sum of r^2 of every row is accumulated into ss_out
+//    [M] (fp32 atomics, one per wave and row), so that no separate pass has to read r again to
+//    normalise it;
+//  * row scale (qkv / gate_up projections, whose weights carry the norm's gamma): every output
+//    row is multiplied by rsqrt(ss_in[row] / K + eps) before bias / SwiGLU, which is the RMSNorm
+//    of the x row moved behind the GEMM:  (x rstd) . (W gamma)^T = rstd (x . (W gamma)^T).
+//
 // Call sites: the MLP's gate_up projection on prefill steps (the reference's
 // F.linear + SiluAndMul, src/myvllm/layers/linear.py:109, src/myvllm/layers/activation.py:8-16),
 // and any projection for which the start-up measurement prefers it to the library.
@@ -68,6 +78,9 @@ struct BigArgs {
     int up_off;                             // SwiGLU: row of W where the up projection starts
     int tiles_m, tiles_n, tiles, ktiles;
     int probe;                              // measurement only: 1 every tile loads tile 0's operands, 2 no stores
+    const float* ss_in;                     // row scale: per-row sum of squares of x (null: off)
+    float rs_eps, rs_inv_k;                 // rstd = rsqrt(ss_in[row] * rs_inv_k + rs_eps)
+    float* ss_out;                          // RES: per-row sum of squares of the new residual (zeroed by the caller)
 };
 
 template <int N>
@@ -89,9 +102,10 @@ struct BigSrc {
     uint32_t a[2][2], b[2][2];              // [half][piece]
 };
 
-template <int CODE, bool SWI>
+template <int CODE, bool SWI, bool RES = false, bool RS = false>
 __global__ __launch_bounds__(kBigThreads) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void big_gemm_kernel(BigArgs a) {
+    static_assert(!(SWI && RES), "the residual epilogue belongs to the plain projections");
     using DT = DType<CODE>;
     using vec8 = typename DT::vec8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -298,6 +312,40 @@ void big_gemm_kernel(BigArgs a) {
     // straight from the accumulator layout cost 4x the write requests, which the L2 channels
     // could not absorb (0.6B qkv at 16384 rows: 127 us with them, 98 us without any store).
     char* const ep = smem + 2 * kBuf + wv * 4096;
+    // Operands of the epilogue that come from memory are requested BEFORE the wait that precedes
+    // it (the fragment registers are dead by then), so their latency is paid once per tile,
+    // together with the drain of the DMA queue: the row scales of the lane's 8 rows and, RES,
+    // the 16 residual chunks the lane will add to its 16 output chunks.
+    float rs[2][4];                          // [top / bottom][x block]
+    u32x4_t resv[2][2][4];                   // [top / bottom][x block pair][store]
+    auto out_voff = [&](int tm, int tn, int hb, int blk, int i) -> uint32_t {
+        constexpr int LPRW = SWI ? 4 : 8, RPI = 64 / LPRW;
+        const int col_base = SWI ? tn * 128 + wc * 32 : tn * 256 + wc * 64;
+        const int rr = i * RPI + lane / LPRW;
+        const int row = tm * 256 + hb * 128 + wr * 64 + (SWI ? 0 : blk * 32) + rr;
+        return (uint32_t)row * (uint32_t)(a.o_stride * 2) + (uint32_t)(col_base * 2 + (lane % LPRW) * 16);
+    };
+    auto pre_epilogue = [&](int tm, int tn) {
+        if constexpr (RS) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const int row = tm * 256 + hb * 128 + wr * 64 + 16 * m + frow;
+                    rs[hb][m] = a.ss_in[min(row, a.M - 1)];
+                }
+        }
+        if constexpr (RES) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)     // rows >= M: beyond out_bytes, read as 0
+                        resv[hb][blk][i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
+                            orsrc, (int)out_voff(tm, tn, hb, blk, i), 0, 0));
+        }
+    };
     auto epilogue = [&](int tm, int tn) {
         if (a.probe & 2) {
 #pragma unroll
@@ -330,6 +378,12 @@ void big_gemm_kernel(BigArgs a) {
                 }
             }
         const int orow = lane / LPRW, ochunk = lane % LPRW;
+        if constexpr (RS) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) rs[hb][m] = rsqrtf(rs[hb][m] * a.rs_inv_k + a.rs_eps);
+        }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {                     // top / bottom rows of the wave
             const int ql = hb ? 3 : 0, qr = hb ? 2 : 1;      // left (gate) / right (up) quadrant
@@ -347,12 +401,15 @@ void big_gemm_kernel(BigArgs a) {
                             float r[4];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
+                                float a0 = SWI ? acc[ql][n][m][e] : acc[sd ? qr : ql][n][m][e];
+                                float a1 = SWI ? acc[qr][n][m][e] : 0.f;
+                                if constexpr (RS) { a0 *= rs[hb][m]; a1 *= rs[hb][m]; }
                                 if (SWI) {
-                                    const float g = acc[ql][n][m][e] + bias_v[0][n][e];
-                                    const float up = acc[qr][n][m][e] + bias_v[1][n][e];
+                                    const float g = a0 + bias_v[0][n][e];
+                                    const float up = a1 + bias_v[1][n][e];
                                     r[e] = g * __builtin_amdgcn_rcpf(1.f + __expf(-g)) * up;
                                 } else {
-                                    r[e] = acc[sd ? qr : ql][n][m][e] + bias_v[sd][n][e];
+                                    r[e] = a0 + bias_v[sd][n][e];
                                 }
                             }
                             u32x2_t o;
@@ -368,11 +425,30 @@ void big_gemm_kernel(BigArgs a) {
                 for (int i = 0; i < 4096 / ROWB / RPI; ++i) {
                     const int rr = i * RPI + orow;
                     const int chunk = ochunk ^ (SWI ? ((rr >> 1) & 3) : (rr & 7));
-                    const u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + rr * ROWB + chunk * 16);
+                    u32x4_t v = *reinterpret_cast<const u32x4_t*>(ep + rr * ROWB + chunk * 16);
                     const int row = m0 + hb * 128 + wr * 64 + (SWI ? 0 : blk * 32) + rr;
                     // rows >= M lie beyond out_bytes: the range check drops them
                     const uint32_t voff = (uint32_t)row * (uint32_t)(a.o_stride * 2)
                                           + (uint32_t)(col_base * 2 + ochunk * 16);
+                    if constexpr (RES) {
+                        // the projection was rounded to the storage type (as a stand-alone GEMM
+                        // rounds its output); + residual, rounded again: the new residual
+                        float p[8], q[8];
+                        unpack8<CODE>(v, p);
+                        unpack8<CODE>(resv[hb][blk][i], q);
+                        float ssq = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            p[e] = DT::to_float(DT::from_float(p[e] + q[e]));
+                            ssq += p[e] * p[e];
+                        }
+                        v = pack8<CODE>(p);
+                        // the 8 lanes of a row: sum over this wave's 64 columns, one atomic per row
+                        ssq += __shfl_xor(ssq, 1, 64);
+                        ssq += __shfl_xor(ssq, 2, 64);
+                        ssq += __shfl_xor(ssq, 4, 64);
+                        if (ochunk == 0 && row < a.M) atomicAdd(a.ss_out + row, ssq);
+                    }
                     __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, (int)voff, 0, 0);
                 }
             }
@@ -415,6 +491,7 @@ void big_gemm_kernel(BigArgs a) {
         // every request so far (up to A0 / B0 of the next tile's second K-tile) lands before
         // the stores are issued: loads and stores do not complete in a common order, so a
         // counted wait behind the stores would have to wait for all of them
+        if constexpr (RES || RS) pre_epilogue(tm, tn);
         big_wait_vmcnt<0>();
         epilogue(tm, tn);
         if (nid < 0) break;
@@ -430,9 +507,9 @@ void big_gemm_kernel(BigArgs a) {
     }
 }
 
-template <int CODE, bool SWI>
+template <int CODE, bool SWI, bool RES = false, bool RS = false>
 int big_launch(BigArgs a, hipStream_t st) {
-    auto k = big_gemm_kernel<CODE, SWI>;
+    auto k = big_gemm_kernel<CODE, SWI, RES, RS>;
     static const hipError_t once = hipFuncSetAttribute(
         (const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, kBigLds);
     if (once != hipSuccess) return (int)once;
@@ -453,10 +530,15 @@ int big_launch(BigArgs a, hipStream_t st) {
 // out[M, N_out] = x . W^T (+ bias)  [swiglu: W = [gate; up], N_out = N / 2].
 // K a multiple of 64 and >= 256; N a multiple of 256 (swiglu: N / 2 a multiple of 128); x rows
 // and out rows 16-byte aligned; x, W and out below 2 GiB each (32-bit buffer offsets).
+// ss_in (optional, [M] fp32): every output row is scaled by rsqrt(ss_in[row] / K + eps) before
+// bias / SwiGLU.  ss_out (optional, [M] fp32, zeroed by the caller; plain epilogue only): `out`
+// holds the residual stream on entry, out = round(round(x . W^T + bias) + out) in place, and
+// ss_out[row] += sum of out[row]^2.
 extern "C" int mvl_big_gemm(const void* x, long x_stride, const void* w, const void* bias,
                             void* out, long o_stride, int M, int N, int K, int swiglu, int dtype,
-                            void* stream) {
+                            const float* ss_in, float eps, float* ss_out, void* stream) {
     if (M == 0) return 0;
+    if (ss_out != nullptr && swiglu) return -1;
     if (M < 0 || K % kBigBK != 0 || K < 4 * kBigBK || (dtype != 0 && dtype != 1)) return -1;
     if (swiglu ? (N % 2 != 0 || (N / 2) % 128 != 0) : (N % 256 != 0)) return -1;
     if (x_stride % 8 != 0 || o_stride % 8 != 0) return -1;
@@ -478,7 +560,16 @@ extern "C" int mvl_big_gemm(const void* x, long x_stride, const void* w, const v
     a.ktiles = K / kBigBK;
     static const char* probe_env = getenv("MVL_BIG_PROBE");
     a.probe = probe_env ? atoi(probe_env) : 0;
+    a.ss_in = ss_in; a.rs_eps = eps; a.rs_inv_k = 1.0f / (float)K; a.ss_out = ss_out;
     auto st = (hipStream_t)stream;
+    if (ss_out != nullptr) {
+        if (ss_in != nullptr) return -1;             // one duty per projection
+        return dtype == 0 ? big_launch<0, false, true>(a, st) : big_launch<1, false, true>(a, st);
+    }
+    if (ss_in != nullptr) {
+        if (dtype == 0) return swiglu ? big_launch<0, true, false, true>(a, st) : big_launch<0, false, false, true>(a, st);
+        return swiglu ? big_launch<1, true, false, true>(a, st) : big_launch<1, false, false, true>(a, st);
+    }
     if (dtype == 0) return swiglu ? big_launch<0, true>(a, st) : big_launch<0, false>(a, st);
     return swiglu ? big_launch<1, true>(a, st) : big_launch<1, false>(a, st);
 }

@@ -163,7 +163,11 @@ class ModelRunner:
             load_weights_from_checkpoint(self.model, cfg.checkpoint_path)
         else:
             self.model.init_random_weights(cfg.seed)
-        if self.on_gpu and cfg.fold_norm_weights:
+        fold = cfg.fold_norm_weights
+        if fold is None:
+            fold = self.tp == 1 and not pg.collectives_active()
+        self.norms_folded = bool(self.on_gpu and fold)
+        if self.norms_folded:
             self.model.fold_norm_weights()
         self.sampler = SamplerLayer(seed=cfg.seed)
         self.step_counter = 0
@@ -211,6 +215,7 @@ class ModelRunner:
             m.hidden_size, m.num_heads, m.num_kv_heads, m.head_dim, m.intermediate_size,
             f"tp{self.tp}", self.dtype, f"seqs{self.max_bs}", f"tok{cfg.max_num_batched_tokens}",
             f"dec{int(cfg.tune_decode_gemms)}", f"pre{int(cfg.tune_prefill_gemms)}",
+            f"fold{int(self.norms_folded)}",
             f"p2p{int(pg.custom_all_reduce() is not None)}", f"coll{int(pg.collectives_active())}"))
 
     def _gemm_choice_path(self) -> Optional[str]:
@@ -316,6 +321,17 @@ class ModelRunner:
         rows = [b for b in hip.BIG_ROW_BUCKETS if b // 2 < top]
         self.prefill_gemm_choices = {name: hip.tune_big_gemm(ws, swiglu, rows=rows)
                                      for name, (ws, swiglu) in roles.items()}
+        if self.norms_folded and self.tp == 1 and not pg.collectives_active():
+            # o -> norm -> gate_up and down -> norm -> next layer's qkv as chains: residual add and
+            # row sums of squares in the first GEMM's epilogue, the norm as a row factor in the
+            # second one's, against GEMM + add/norm kernel + GEMM
+            nxt = list(self.model.model.layers)[1:5]
+            self.prefill_gemm_choices["o+norm"] = hip.tune_big_resid(
+                roles["o"][0], roles["gate_up"][0], True, rows=rows, eps=self.cfg.model.rms_norm_epsilon)
+            if nxt:
+                self.prefill_gemm_choices["down+norm"] = hip.tune_big_resid(
+                    roles["down"][0], [l.self_attn.qkv_proj.weight for l in nxt], False, rows=rows,
+                    eps=self.cfg.model.rms_norm_epsilon)
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         if self.rank == 0 and self.cfg.log_stats:

@@ -150,7 +150,7 @@ class RowParallelLinear(LinearBase):
         shard = param.data.size(1)
         param.data.copy_(loaded_weight.narrow(1, self.tp_rank * shard, shard))
 
-    def forward(self, x, defer_reduce: bool = False):
+    def forward(self, x, defer_reduce: bool = False, residual=None):
         """``defer_reduce``: the caller hands the result to ``ops.norm_linear`` / ``RMSNorm``
         with a residual and to nothing else.  Under the peer-to-peer all-reduce the partial sum
         of a decode-sized output is then returned as ``ops.PendingReduce`` and that consumer
@@ -158,7 +158,9 @@ class RowParallelLinear(LinearBase):
         reduce-scatter (chunk-pipelined against the GEMM) and the consumer norms this rank's rows
         only before gathering them (``pg.can_defer_reduce``).  The same flag lets a K-split decode GEMM
         hand its unsummed slices (``ops.SplitKPartials``) on: to the norm on a single rank, to
-        the reducing kernel (which sums them while staging) otherwise."""
+        the reducing kernel (which sums them while staging) otherwise.  ``residual`` (one rank):
+        the stream that norm will add the result to, so that a prefill-sized projection can add it
+        in its own epilogue (``ops.ResidualSum``)."""
         bias = self.bias if self.tp_rank == 0 else None
         if (self.tp_size > 1 or pg.collectives_active()) and self.reduce_results:
             from minivllm_amd.parallel.overlap import row_parallel_linear, row_parallel_linear_scatter
@@ -169,4 +171,5 @@ class RowParallelLinear(LinearBase):
             if how == "scatter":         # prefill-sized: the sum leaves as a reduce-scatter
                 return ops.PendingReduce(scattered=row_parallel_linear_scatter(x, self.weight, bias))
             return row_parallel_linear(x, self.weight, bias)
-        return ops.linear(x, self.weight, bias, to_norm=defer_reduce and x.dim() == 2)
+        return ops.linear(x, self.weight, bias, to_norm=defer_reduce and x.dim() == 2,
+                          residual=residual if torch.is_tensor(residual) else None)

@@ -65,11 +65,11 @@ class Qwen3Attention(nn.Module):
         return self.attend(positions, self.qkv_proj(hidden))
 
     def attend(self, positions: torch.Tensor, qkv: torch.Tensor,
-               defer_reduce: bool = False) -> torch.Tensor:
+               defer_reduce: bool = False, residual=None) -> torch.Tensor:
         """Everything after the QKV projection (the decoder layer may have produced ``qkv``
         together with the preceding norm in one kernel).  ``defer_reduce``: the caller feeds
         the result into a norm with a residual, which may take over the TP all-reduce
-        (``RowParallelLinear.forward``)."""
+        (``RowParallelLinear.forward``); ``residual``: the stream it will be added to."""
         ctx = get_context()
         cos_sin = self._rope[0].cos_sin_cache
         q_weight = self.q_norm.weight if self.use_qk_norm else None
@@ -86,7 +86,7 @@ class Qwen3Attention(nn.Module):
             self.attn.k_cache, self.attn.v_cache, ctx.slot_mapping, skip_q=fuse,
             k_in_place=k_in_place)
         o = self.attn(q, k, v, q_rope=(positions, cos_sin, q_weight, self.eps) if fuse else None)
-        return self.o_proj(o, defer_reduce=defer_reduce)
+        return self.o_proj(o, defer_reduce=defer_reduce, residual=residual)
 
 
 class Qwen3MLP(nn.Module):
@@ -120,10 +120,10 @@ class Qwen3DecoderLayer(nn.Module):
                                         qkv_proj.bias, gamma_folded=n1.folded)
         # o and down hand their result to the norm behind them and to nothing else, so they may
         # leave work to it (ops.PendingReduce / ops.SplitKPartials instead of a tensor)
-        hidden = self.self_attn.attend(positions, qkv, defer_reduce=True)
+        hidden = self.self_attn.attend(positions, qkv, defer_reduce=True, residual=residual)
         act, residual = ops.norm_linear(hidden, residual, n2.weight, n2.eps, gate_up.weight,
                                         gate_up.bias, swiglu=True, gamma_folded=n2.folded)
-        return self.mlp.down_proj(act, defer_reduce=True), residual
+        return self.mlp.down_proj(act, defer_reduce=True, residual=residual), residual
 
     def fold_norm_weights(self) -> None:
         self.input_layernorm.fold_into(self.self_attn.qkv_proj.weight)

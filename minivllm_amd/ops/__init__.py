@@ -9,7 +9,7 @@ import torch
 import torch.nn.functional as F
 
 from . import torch_ref
-from .partials import PendingReduce, ResidualShard, ScatteredRows, SplitKPartials
+from .partials import PendingReduce, ResidualShard, ResidualSum, ScatteredRows, SplitKPartials
 
 
 def _hip():
@@ -22,6 +22,8 @@ def _on_gpu(t: torch.Tensor) -> bool:
 
 
 def rms_norm(x, weight, eps):
+    if isinstance(x, ResidualSum):
+        x = x.r
     if isinstance(x, PendingReduce):
         return _reduce_add_rms_norm(x, None, weight, eps)[0]
     if _is_partials(x):
@@ -43,6 +45,8 @@ def add_rms_norm(x, residual, weight, eps):
     pending work (``PendingReduce``: all-reduce still to do; ``SplitKPartials``: K slices still
     to sum), which the norm then takes over; ``r`` may come back as a ``ResidualShard`` (and be
     passed in as one) when the reduce ran as the two-shot peer-to-peer kernel."""
+    if isinstance(x, ResidualSum):          # the residual is already in: norm the stream
+        return rms_norm(x.r, weight, eps), x.r
     if isinstance(x, PendingReduce):
         return _reduce_add_rms_norm(x, residual, weight, eps)
     if isinstance(residual, ResidualShard):
@@ -120,13 +124,17 @@ def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scal
                                                        context_lens, scale))
 
 
-def linear(x, weight, bias=None, to_norm=False):
+def linear(x, weight, bias=None, to_norm=False, residual=None):
     """``x @ weight.T (+ bias)``: the library GEMM, except for the GPU inputs (<= 16 rows: skinny
     kernel; 17..256 rows: mid-batch kernel; more: the 256 x 256-tile prefill kernel) of the
     shapes where the hand-written kernels were measured to be faster on this machine.  ``to_norm``: the
     caller passes the result straight to ``norm_linear`` / ``add_rms_norm`` (and to nothing
     else), which lets a K-split mid-batch GEMM hand over its unsummed slices
-    (``SplitKPartials``) for the norm kernel to sum."""
+    (``SplitKPartials``) for the norm kernel to sum.  ``residual`` (with ``to_norm``): the
+    stream that norm will add the result to; a prefill-sized GPU projection may then add it in
+    its own epilogue and return ``ResidualSum`` (the stream, updated in place, and its row sums
+    of squares), which ``norm_linear`` / ``add_rms_norm`` / ``rms_norm`` accept in place of a
+    tensor."""
     if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 256:
         h = _hip()
         if x.shape[0] <= 16:
@@ -139,8 +147,12 @@ def linear(x, weight, bias=None, to_norm=False):
             c = h.mid_gemm_choice(x, weight, to_norm=to_norm)
             if c is not None:
                 return h.mid_linear(x, weight, bias, False, c[0], c[1], c[2], defer=to_norm)
-    elif _on_gpu(x) and x.dim() == 2 and _hip().big_gemm_pays(x, weight):
-        return _hip().big_linear(x, weight, bias)
+    elif _on_gpu(x) and x.dim() == 2:
+        h = _hip()
+        if to_norm and residual is not None and h.big_gemm_resid_pays(x, weight, residual):
+            return h.big_linear_resid(x, weight, bias, residual)
+        if h.big_gemm_pays(x, weight):
+            return h.big_linear(x, weight, bias)
     return F.linear(x, weight, bias)
 
 
@@ -176,6 +188,12 @@ def norm_linear(x, residual, gamma, eps, weight, bias=None, swiglu=False, gamma_
     was multiplied by ``gamma`` along its input dimension at load time (``gamma`` itself is all
     ones then); only such weights can take the one-kernel path, every other case runs the norm
     kernel followed by the projection."""
+    if isinstance(x, ResidualSum):                     # residual added + squares summed by the GEMM
+        r = x.r
+        if gamma_folded and _hip().big_gemm_ok(r, weight, swiglu):
+            return _hip().big_linear(r, weight, bias, swiglu, row_ss=x.ss, eps=eps), r
+        h = rms_norm(r, gamma, eps)
+        return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), r
     if isinstance(x, PendingReduce):                   # row-parallel partial sum: reduce here
         h, residual = _reduce_add_rms_norm(x, residual, gamma, eps)
         return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), residual

@@ -14,7 +14,7 @@ from typing import Optional, Tuple
 
 import torch
 
-from .partials import SplitKPartials      # the type lives where CPU-only code can import it
+from .partials import ResidualSum, SplitKPartials      # the types live where CPU-only code can import them
 
 _LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
                          "_hip_kernels.so")
@@ -78,7 +78,7 @@ _mid = _sig("mvl_mid_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long
             _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void)
 
 _big = _sig("mvl_big_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_int, _c_int,
-            _c_int, _c_int, _c_int, _c_void)
+            _c_int, _c_int, _c_int, _c_void, _c_float, _c_void, _c_void)
 
 _mid_eff_splits = _lib.mvl_mid_effective_splits
 _mid_eff_splits.argtypes = [_c_int, _c_int]
@@ -1009,10 +1009,13 @@ def tune_big_gemm(weights, swiglu: bool = False, rows=BIG_ROW_BUCKETS, margin: f
 
 
 def big_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               swiglu: bool = False, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+               swiglu: bool = False, out: Optional[torch.Tensor] = None,
+               row_ss: Optional[torch.Tensor] = None, eps: float = 0.0) -> torch.Tensor:
     """``x @ weight.T (+ bias)``, or with ``swiglu`` ``silu(x @ Wg.T) * (x @ Wu.T)`` of the fused
     ``[Wg; Wu]`` weight, on the compute-bound 256 x 256-tile MFMA kernel (any row count; built
-    for prefill steps)."""
+    for prefill steps).  ``row_ss`` ([M] fp32: the sum of squares of every x row): the rows of
+    the product are multiplied by ``rsqrt(row_ss / K + eps)`` before bias / SwiGLU, i.e. ``x`` is
+    RMS-normalised behind the GEMM (for a ``weight`` that carries the norm's gamma)."""
     if not big_gemm_ok(x, weight, swiglu):
         raise ValueError(f"big_linear cannot take x {tuple(x.shape)} / weight {tuple(weight.shape)}")
     M, K = x.shape
@@ -1023,9 +1026,89 @@ def big_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     assert out.shape == (M, n_out) and out.stride(1) == 1 and out.stride(0) % 8 == 0 and out.dtype == x.dtype
     if bias is not None:
         assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
+    if row_ss is not None:
+        assert row_ss.dtype == torch.float32 and row_ss.numel() == M and row_ss.is_contiguous()
     _check(_big(x.data_ptr(), x.stride(0), weight.data_ptr(),
                 bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
-                M, N, K, int(swiglu), _dt(x), _stream()), "big_gemm")
+                M, N, K, int(swiglu), _dt(x), row_ss.data_ptr() if row_ss is not None else None,
+                float(eps), None, _stream()), "big_gemm")
+    return out
+
+
+def big_resid_ok(x: torch.Tensor, weight: torch.Tensor, residual) -> bool:
+    """Operands of ``big_linear_resid``: a plain ``big_gemm_ok`` projection onto a contiguous,
+    16-byte aligned [M, N] residual stream of the same dtype."""
+    return (torch.is_tensor(residual) and big_gemm_ok(x, weight) and residual.dim() == 2
+            and tuple(residual.shape) == (x.shape[0], weight.shape[0]) and residual.dtype == x.dtype
+            and residual.stride(1) == 1 and residual.stride(0) % 8 == 0
+            and residual.data_ptr() % 16 == 0
+            and residual.shape[0] * residual.stride(0) * 2 < (1 << 31))
+
+
+def big_linear_resid(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
+                     residual: torch.Tensor) -> ResidualSum:
+    """``residual <- round(round(x @ weight.T + bias) + residual)`` in place (the roundings of a
+    GEMM followed by the fused add + norm kernel) and, from the same epilogue, the sum of squares
+    of every new residual row: what a following RMSNorm needs, without a pass over the rows."""
+    if not big_resid_ok(x, weight, residual):
+        raise ValueError("big_linear_resid cannot take these operands")
+    M, K = x.shape
+    N = weight.shape[0]
+    ss = torch.zeros(M, dtype=torch.float32, device=x.device)
+    _check(_big(x.data_ptr(), x.stride(0), weight.data_ptr(),
+                bias.data_ptr() if bias is not None else None, residual.data_ptr(),
+                residual.stride(0), M, N, K, 0, _dt(x), None, 0.0, ss.data_ptr(), _stream()),
+           "big_gemm (residual epilogue)")
+    return ResidualSum(residual, ss)
+
+
+def big_gemm_resid_pays(x: torch.Tensor, weight: torch.Tensor, residual) -> bool:
+    """True when a projection that feeds (residual add + RMSNorm) should run with the residual
+    epilogue: prefill-sized, operands the kernel takes, and a start-up measurement of the whole
+    chain (projection, norm, next projection) that preferred the fused form."""
+    if x.dim() != 2 or x.shape[0] < BIG_MIN_ROWS:
+        return False
+    n, k = weight.shape
+    return bool(_BIG_CHOICE.get((big_row_bucket(x.shape[0]), n, k, "resid"))) \
+        and big_resid_ok(x, weight, residual)
+
+
+def tune_big_resid(prod_weights, cons_weights, cons_swiglu: bool, rows=BIG_ROW_BUCKETS,
+                   eps: float = 1e-6, margin: float = 0.985) -> dict:
+    """For a projection that feeds (residual add + RMSNorm) and the projection behind that norm
+    (o -> gate_up, down -> qkv; ``cons_weights`` carry the norm's gamma): time the chain as it runs
+    unfused (best plain projection, add + norm kernel, best next projection) against the fused
+    chain (residual epilogue, row-scaled next projection) at each row count and record the winner
+    under ``"resid"``.  Returns {rows: (unfused us, fused us, use fused)}."""
+    import torch.nn.functional as F
+    from . import linear as _linear, swiglu_linear as _swiglu_linear
+    pairs = list(zip(list(prod_weights)[:4], list(cons_weights)[:4]))
+    n, k = pairs[0][0].shape
+    nc = pairs[0][1].shape[0]
+    dtype, dev = pairs[0][0].dtype, pairs[0][0].device
+    gamma = torch.ones(n, dtype=dtype, device=dev)
+    out = {}
+    for m in rows:
+        x = torch.randn(m, k, dtype=dtype, device=dev)
+        resid = torch.zeros(m, n, dtype=dtype, device=dev)
+        if not big_resid_ok(x, pairs[0][0], resid) or not big_gemm_ok(resid, pairs[0][1], cons_swiglu):
+            return out
+
+        def unfused(xx, pair):
+            h, r = add_rms_norm(_linear(xx, pair[0]), resid, gamma, eps)
+            return _swiglu_linear(h, pair[1]) if cons_swiglu else _linear(h, pair[1])
+
+        def fused(xx, pair):
+            rs = big_linear_resid(xx, pair[0], None, resid)
+            return big_linear(rs.r, pair[1], None, cons_swiglu, row_ss=rs.ss, eps=eps)
+        reps = max(1, min(8, int(2e11 / (2.0 * m * (n * k + nc * n)))))
+        t_a = _graph_time_ms(unfused, x, pairs, reps)
+        resid.zero_()
+        t_b = _graph_time_ms(fused, x, pairs, reps)
+        use = t_b < t_a * margin
+        _BIG_CHOICE[(big_row_bucket(m), n, k, "resid")] = use
+        out[m] = (round(t_a * 1e3, 1), round(t_b * 1e3, 1), use)
+        del x, resid
     return out
 
 

@@ -288,3 +288,54 @@ def test_prefill_graphs_of_many_sequences_match_eager(gpu, num_seqs):
     print(f"[{num_seqs} sequences] prefill graph vs eager, relative logit error per step: {errs}")
     assert max(errs) < REL_TOL_SAME, errs
     e.exit(); g.exit()
+
+
+def test_prefill_with_norms_folded_into_the_gemm_epilogues(gpu):
+    """Prefill with no (residual add + RMSNorm) pass in the layer loop: o / down add the residual
+    stream and sum the squares of the new rows in their epilogue, qkv / gate_up (weights carrying
+    the norms' gamma) scale their output rows.  Forced on for every prefill row bucket here (the
+    engine decides by measurement); logits of two prefill steps (one behind a cached prefix)
+    against the fp32 oracle carrying the same folded weights and against the unfused GPU path."""
+    from minivllm_amd.engine.model_runner import ModelRunner
+    from minivllm_amd.ops import hip
+    kw = dict(max_num_batched_tokens=4096, prefill_graph_max_tokens=0)
+    g = ModelRunner(_cfg("16q8kv", **kw), 0)
+    assert g.norms_folded
+    c = ModelRunner(_cfg("16q8kv", device="cpu", dtype=torch.float32, **kw), 0)
+    c.model.load_state_dict({k: v.float().cpu() for k, v in g.model.state_dict().items()})
+    prompts = _prompts((700, 300, 1000, 257, 64, 513), 11)
+    second = [p[:512] + _prompts((90,), 12 + i)[0] for i, p in enumerate(prompts[:3])]   # 2 cached blocks each
+    calls = {"n": 0}
+    orig = hip.big_linear_resid
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return orig(*a, **k)
+    saved = dict(hip._BIG_CHOICE)
+    layer = g.model.model.layers[0]
+    shapes = [tuple(layer.self_attn.o_proj.weight.shape), tuple(layer.mlp.down_proj.weight.shape)]
+    out = {}
+    try:
+        hip.big_linear_resid = counted
+        for name, r, force in (("unfused", g, False), ("fused", g, True), ("cpu", c, False)):
+            for b in hip.BIG_ROW_BUCKETS:
+                for n, k in shapes:
+                    hip._BIG_CHOICE[(b, n, k, "resid")] = force
+            d = _Driver(r)
+            logs = []
+            for batch in (prompts, second):
+                seqs = d.seqs(batch)
+                r.run(seqs, True)
+                logs.append(r._last_step_logits[:len(seqs)].float().cpu())
+            out[name] = logs
+    finally:
+        hip.big_linear_resid = orig
+        hip._BIG_CHOICE.clear()
+        hip._BIG_CHOICE.update(saved)
+    n_layers = g.cfg.model.num_layers
+    assert calls["n"] == 2 * 2 * n_layers, calls            # o and down of every layer, two steps
+    vs_oracle = [_rel_err(a, b) for a, b in zip(out["fused"], out["cpu"])]
+    vs_unfused = [_rel_err(a, b) for a, b in zip(out["fused"], out["unfused"])]
+    print(f"folded-norm prefill: vs oracle {vs_oracle}, vs unfused kernels {vs_unfused}")
+    assert max(vs_oracle) < REL_TOL and max(vs_unfused) < REL_TOL_SAME
+    g.exit(); c.exit()

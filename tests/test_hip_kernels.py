@@ -1186,3 +1186,97 @@ def test_paged_prefill_from_a_work_list(hip, hq, hkv, d, bs):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out3[:T10], out[:T10]) and not out3[T10:].any()
+
+
+# ------------------------------- prefill GEMM epilogues that absorb residual add + RMSNorm
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("M", [257, 1000, 4096])
+@pytest.mark.parametrize("N,K", [(1024, 2048), (1024, 3072), (4096, 4096), (4096, 12288), (5120, 3200)])
+def test_big_gemm_residual_epilogue(hip, dtype, M, N, K):
+    """o / down projection with the residual stream added in the epilogue (in place) and the
+    sum of squares of every new row accumulated by atomics: against GEMM, add and square sum in
+    fp32; rows beyond M untouched; with and without bias."""
+    if K % 64:
+        pytest.skip("K must be a multiple of 64")
+    torch.manual_seed(61)
+    x = torch.randn(M, K, device=DEV, dtype=dtype)
+    w = (torch.randn(N, K, device=DEV) * 0.03).to(dtype)
+    b = torch.randn(N, device=DEV, dtype=dtype) if M == 1000 else None
+    buf = torch.randn(M + 1, N, device=DEV, dtype=dtype)
+    res0 = buf[:M].clone()
+    guard = buf[M].clone()
+    y = x.float() @ w.float().T + (b.float() if b is not None else 0)
+    want = y.to(dtype).float() + res0.float()
+    rs = hip.big_linear_resid(x, w, b, buf[:M])
+    assert rs.r.data_ptr() == buf.data_ptr() and torch.equal(buf[M], guard)
+    close(rs.r, want, dtype, 4)
+    ss_ref = rs.r.float().pow(2).sum(-1)                    # of the values actually stored
+    assert float(((rs.ss - ss_ref).abs() / ss_ref).max()) < 2e-3
+    # the same call as the unfused pair of kernels would leave it
+    r2 = res0.clone()
+    hip.add_rms_norm(hip.big_linear(x, w, b), r2, torch.ones(N, device=DEV, dtype=dtype), 1e-6)
+    assert float((rs.r.float() - r2.float()).abs().max()) <= 2 * float(r2.float().abs().max()) * (2 ** -7)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("swiglu", [False, True])
+@pytest.mark.parametrize("M", [300, 2048])
+def test_big_gemm_row_scale_epilogue(hip, dtype, swiglu, M):
+    """qkv / gate_up projection of an un-normalised x with the RMSNorm applied as a per-row factor
+    behind the GEMM (weights carry gamma): against norm-then-GEMM in fp32 and against the
+    unfused kernels."""
+    torch.manual_seed(62)
+    K, N, eps = 1024, 2048, 1e-6
+    x = (torch.randn(M, K, device=DEV) * 3.0).to(dtype)
+    gamma = (1 + 0.1 * torch.randn(K, device=DEV)).to(dtype)
+    w = (torch.randn(N, K, device=DEV) * 0.03).to(dtype)
+    wg = (w.float() * gamma.float()[None]).to(dtype)          # gamma folded into the weights
+    ss = x.float().pow(2).sum(-1)
+    got = hip.big_linear(x, wg, None, swiglu, row_ss=ss, eps=eps)
+    xn = x.float() * torch.rsqrt(ss / K + eps)[:, None]
+    y = xn @ wg.float().T
+    want = torch.nn.functional.silu(y[:, :N // 2]) * y[:, N // 2:] if swiglu else y
+    close(got, want, dtype, 4)
+    h = hip.rms_norm(x, gamma, eps)
+    unfused = hip.silu_and_mul(hip.big_linear(h, w)) if swiglu else hip.big_linear(h, w)
+    close(got, unfused.float(), dtype, 6)
+
+
+def test_ops_residual_sum_chain(hip):
+    """ops level: with the measured choice set, a projection handed its residual returns
+    ``ResidualSum`` and ``norm_linear`` consumes it (row-scaled GEMM when the weights carry gamma,
+    norm kernel + GEMM otherwise); both against the unfused chain."""
+    from minivllm_amd import ops
+    torch.manual_seed(63)
+    dtype, M, H, Ko, I, eps = torch.bfloat16, 1024, 1024, 2048, 1536, 1e-6
+    x = torch.randn(M, Ko, device=DEV, dtype=dtype)
+    wo = (torch.randn(H, Ko, device=DEV) * 0.03).to(dtype)
+    gamma = (1 + 0.1 * torch.randn(H, device=DEV)).to(dtype)
+    wgu = (torch.randn(2 * I, H, device=DEV) * 0.03).to(dtype)
+    wgu_folded = (wgu.float() * gamma.float()[None]).to(dtype)
+    ones = torch.ones(H, device=DEV, dtype=dtype)
+    res = torch.randn(M, H, device=DEV, dtype=dtype)
+    h_ref, r_ref = hip.add_rms_norm(torch.nn.functional.linear(x, wo), res.clone(), gamma, eps)
+    want = hip.silu_and_mul(torch.nn.functional.linear(h_ref, wgu)).float()
+    key = (hip.big_row_bucket(M), H, Ko, "resid")
+    saved = dict(hip._BIG_CHOICE)
+    try:
+        hip._BIG_CHOICE[key] = True
+        r1 = res.clone()
+        y = ops.linear(x, wo, None, to_norm=True, residual=r1)
+        assert isinstance(y, ops.ResidualSum) and y.r.data_ptr() == r1.data_ptr()
+        act, r_out = ops.norm_linear(y, r1, ones, eps, wgu_folded, None, swiglu=True, gamma_folded=True)
+        assert r_out.data_ptr() == r1.data_ptr()
+        close(act, want, dtype, 8)
+        close(r_out, r_ref.float(), dtype, 4)
+        r2 = res.clone()
+        y = ops.linear(x, wo, None, to_norm=True, residual=r2)
+        act2, _ = ops.norm_linear(y, r2, gamma, eps, wgu, None, swiglu=True, gamma_folded=False)
+        close(act2, want, dtype, 8)
+        hn, rr = ops.add_rms_norm(ops.linear(x, wo, None, to_norm=True, residual=res.clone()), None, gamma, eps)
+        close(hn, h_ref.float(), dtype, 4)
+        hip._BIG_CHOICE[key] = False
+        assert torch.is_tensor(ops.linear(x, wo, None, to_norm=True, residual=res.clone()))
+    finally:
+        hip._BIG_CHOICE.clear()
+        hip._BIG_CHOICE.update(saved)
