@@ -220,7 +220,10 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
 
     # ------------------------------------------------------------- decode phase
     if args.mode in ("both", "decode"):
-        sp = SamplingParams(temperature=0.6, max_tokens=W + K + 1, ignore_eos=True)
+        # the sequences outlive the timed window by a few tokens: with launch-ahead decode the step
+        # after the last timed one must exist, so that the window starts and ends in the same
+        # pipeline state (one step in flight) and contains exactly K steps of GPU work
+        sp = SamplingParams(temperature=0.6, max_tokens=W + K + 4, ignore_eos=True)
         for p in prompts(B, S):
             eng.add_prompt(p, sp)
         while eng.scheduler.waiting or eng.scheduler.prefilling:   # untimed: prefill all B prompts
