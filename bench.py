@@ -290,14 +290,18 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
     return res
 
 
-def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int):
+def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int, conservative: bool = False,
+                port_shift: int = 0):
     """Run ``phase`` in a child process of this rank (the children of all ranks form the job of
-    that phase).  Returns rank 0's result dict, or {'error': ...}."""
+    that phase).  Returns rank 0's result dict, or {'error': ...}.  ``conservative``: the engine's
+    newer multi-rank paths off (MINIVLLM_TP_CONSERVATIVE, see ModelRunner)."""
     env = dict(os.environ)
+    if conservative:
+        env["MINIVLLM_TP_CONSERVATIVE"] = "1"
     for k in [k for k in env if k.startswith("TORCHELASTIC_")]:
         env.pop(k)                               # the child hosts its own rendezvous store
     env["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", args.port))
-                             + PHASE_PORT_OFFSET[phase])
+                             + PHASE_PORT_OFFSET[phase] + port_shift)
     env.update(RANK=str(rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world),
                MINIVLLM_BENCH_PHASE=phase)
     if phase == "tpc":                           # TP again, all-reduce by the peer-to-peer kernel
@@ -526,6 +530,26 @@ def main():
     # ---- N > 1: orchestrate one child per phase --------------------------------------
     # headline first: whatever happens to the side phases, its number exists by then
     tp = None if args.no_tp else spawn_phase(args, "tp", rank, local_rank, world)
+    tp_first = None
+    if tp is not None:
+        # a failed tensor-parallel phase is tried once more with the engine's newer multi-rank
+        # paths off.  Rank 0's verdict decides for everybody (only its child prints the numbers),
+        # published through a key-value store next to the launcher's rendezvous port.
+        retry = False
+        try:
+            import datetime
+            from torch.distributed import TCPStore
+            store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                             int(os.environ.get("MASTER_PORT", args.port)) + 555, world, rank == 0,
+                             timeout=datetime.timedelta(seconds=120))
+            if rank == 0:
+                store.set("tp_retry", "1" if not phase_ok(tp) else "0")
+            retry = store.get("tp_retry") == b"1"
+        except Exception as e:                   # no vote, no retry
+            print(f"[bench] rank {rank}: retry vote unavailable ({e!r})", file=sys.stderr, flush=True)
+        if retry:
+            tp_first = tp
+            tp = spawn_phase(args, "tp", rank, local_rank, world, conservative=True, port_shift=37)
     want_long = args.long_context == "on" or (args.long_context == "auto" and world == 8)
     long_ctx = (spawn_phase(args, "l32k", rank, local_rank, world)
                 if want_long and not args.no_tp else None)
@@ -535,6 +559,10 @@ def main():
     if rank != 0:
         return
     out, good = assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common, long_ctx)
+    if tp_first is not None:
+        out["tensor_parallel_first_attempt"] = tp_first
+        out["tensor_parallel_retry"] = "conservative engine settings (MINIVLLM_TP_CONSERVATIVE=1)"
+    out["gpu_state"] = gpu_state()
     print(json.dumps(out), flush=True)
     if not good:
         sys.exit(1)

@@ -114,6 +114,14 @@ class ModelRunner:
         ``loop()`` at the end of construction when ``spawn_loop`` is set."""
         self.cfg: EngineConfig = as_engine_config(config)
         cfg = self.cfg
+        if cfg.world_size > 1 and os.environ.get("MINIVLLM_TP_CONSERVATIVE") == "1":
+            # Fallback for a multi-GPU run whose first attempt failed (bench.py retries a failed
+            # tensor-parallel phase this way): the newer multi-rank paths off - no decode step
+            # launched ahead on the workers, plain all-reduce in front of every norm, prefill
+            # graphs only for the shapes captured at start-up
+            import dataclasses
+            self.cfg = cfg = dataclasses.replace(cfg, decode_prelaunch=False, prefill_graph_lazy=False,
+                                                 scatter_norm_min_rows=1 << 30)
         self.rank = rank
         self.world_size = cfg.world_size       # processes of this engine
         self.tp = cfg.tp_degree                # ways the model is sharded (a shard rehearsal: > processes)
