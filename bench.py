@@ -541,7 +541,7 @@ def main():
             from torch.distributed import TCPStore
             store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
                              int(os.environ.get("MASTER_PORT", args.port)) + 555, world, rank == 0,
-                             timeout=datetime.timedelta(seconds=120))
+                             timeout=datetime.timedelta(seconds=args.phase_timeout + 90))
             if rank == 0:
                 store.set("tp_retry", "1" if not phase_ok(tp) else "0")
             retry = store.get("tp_retry") == b"1"

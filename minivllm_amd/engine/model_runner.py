@@ -447,8 +447,14 @@ class ModelRunner:
 
     def loop(self) -> None:
         """Worker main loop: execute broadcast requests until ``exit``."""
+        from minivllm_amd.engine.rpc import ChannelClosed
         while True:
-            method, scalars, arrays = self.channel.recv(self.rank - 1)
+            try:
+                method, scalars, arrays = self.channel.recv(self.rank - 1)
+            except ChannelClosed as e:       # rank 0 died: nobody will ever send 'exit'
+                print(f"[runner] rank {self.rank}: {e}; shutting down", flush=True)
+                self.exit(peers_dead=True)
+                raise SystemExit(3)
             if method == "run_batch":
                 self._spec = None
                 b = Batch(arrays=arrays, **scalars)

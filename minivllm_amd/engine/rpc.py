@@ -11,7 +11,8 @@ acknowledgement words, addressed by *name* so that any process can attach:
 
     [0]  seq      (u64)  bumped by the writer after the payload is complete
     [1]  nbytes   (u64)
-    [2..2+R) ack  (u64)  reader r stores the last seq it has fully consumed
+    [2]  pid      (u64)  of the writer: an idle reader checks now and then that it still exists
+    [3..3+R) ack  (u64)  reader r stores the last seq it has fully consumed
     payload bytes
 
 The writer waits until every reader has acknowledged message ``seq-1`` before it touches the
@@ -20,6 +21,7 @@ followed by raw array bytes; batch tensors are never pickled element-wise.
 """
 from __future__ import annotations
 
+import os
 import pickle
 import struct
 import time
@@ -28,7 +30,7 @@ from typing import Any, Dict, Tuple
 
 import numpy as np
 
-_HDR_WORDS = 2
+_HDR_WORDS = 3
 
 
 class ChannelTimeout(RuntimeError):
@@ -76,6 +78,10 @@ def _attach_untracked(name: str) -> shared_memory.SharedMemory:
         resource_tracker.register = orig
 
 
+class ChannelClosed(RuntimeError):
+    """The writer of a control channel has exited without saying goodbye."""
+
+
 class ShmBroadcastChannel:
     def __init__(self, name: str, num_readers: int, create: bool, size: int = 8 << 20,
                  attach_timeout_s: float = 120.0):
@@ -93,6 +99,7 @@ class ShmBroadcastChannel:
             self.shm = shared_memory.SharedMemory(name=name, create=True,
                                                   size=self._ctrl_bytes + size)
             self.shm.buf[:self._ctrl_bytes] = bytes(self._ctrl_bytes)
+            np.ndarray((3,), dtype=np.uint64, buffer=self.shm.buf[:24])[2] = os.getpid()
         else:
             deadline = time.monotonic() + attach_timeout_s
             while True:
@@ -149,17 +156,35 @@ class ShmBroadcastChannel:
         deadline = None if timeout_s is None else time.monotonic() + timeout_s
         want = self._seq + 1
         spins = 0
+        next_alive_check = time.monotonic() + 1.0
         while int(self._ctrl[0]) < want:
             spins += 1
             if spins > 2000:
                 time.sleep(0.0001)
-            if deadline is not None and time.monotonic() > deadline:
-                raise ChannelTimeout("no control message")
+                now = time.monotonic()
+                if deadline is not None and now > deadline:
+                    raise ChannelTimeout("no control message")
+                if now > next_alive_check:           # an idle reader: is the writer still there?
+                    next_alive_check = now + 1.0
+                    if not self.writer_alive():
+                        raise ChannelClosed("the driving rank's process is gone")
         n = int(self._ctrl[1])
         msg = decode_message(self._payload[:n])
         self._seq = want
         self._ctrl[_HDR_WORDS + reader_index] = want     # acknowledge
         return msg
+
+    def writer_alive(self) -> bool:
+        pid = int(self._ctrl[2])
+        if pid == 0:
+            return True
+        try:
+            os.kill(pid, 0)
+        except ProcessLookupError:
+            return False
+        except PermissionError:
+            return True
+        return True
 
     def close(self) -> None:
         self._ctrl = None

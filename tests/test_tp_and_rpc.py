@@ -3,6 +3,7 @@ the shared-memory control channel across processes, and the full engine at world
 over gloo on CPU (TP=2 tokens == TP=1 tokens)."""
 import multiprocessing as mp
 import os
+import time
 
 import numpy as np
 import pytest
@@ -422,3 +423,44 @@ def test_prefill_reduce_scatter_norm_all_gather_matches_tp1(world, chunks):
     one, used1 = run(1, port + 1)
     assert used >= 4 and used1 == 0, (used, used1)        # 2 layers: o, down, o, down (into the final norm)
     assert many == one
+
+
+def _writer_that_dies(name, q):
+    from minivllm_amd.engine.rpc import ShmBroadcastChannel
+    ch = ShmBroadcastChannel(name, 1, create=True)
+    ch.send("hello", {"x": 1})
+    q.put("sent")
+    q.close()
+    q.join_thread()                               # the message has left this process
+    os._exit(0)                                   # no goodbye, the segment stays behind
+
+
+def test_an_idle_reader_notices_that_the_writer_is_gone():
+    """A worker waiting for its next request must not wait forever for a rank 0 that crashed:
+    the channel header carries the writer's pid and an idle reader checks it once a second."""
+    import multiprocessing as mp
+    from minivllm_amd.engine.rpc import ChannelClosed, ShmBroadcastChannel
+    name = f"mvl_test_dead_writer_{os.getpid()}"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_writer_that_dies, args=(name, q))
+    p.start()
+    assert q.get(timeout=60) == "sent"
+    reader = ShmBroadcastChannel(name, 1, create=False)
+    try:
+        method, scalars, _ = reader.recv(0, timeout_s=30)
+        assert method == "hello" and scalars == {"x": 1}
+        p.join(timeout=30)
+        t0 = time.monotonic()
+        with pytest.raises(ChannelClosed):
+            reader.recv(0, timeout_s=30)
+        assert time.monotonic() - t0 < 10
+    finally:
+        reader.close()
+        from multiprocessing import shared_memory
+        try:
+            seg = shared_memory.SharedMemory(name=name)
+            seg.close()
+            seg.unlink()
+        except FileNotFoundError:
+            pass
