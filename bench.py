@@ -528,10 +528,12 @@ def main():
         return
 
     # ---- N > 1: orchestrate one child per phase --------------------------------------
+    if rank == 0:
+        print(f"[bench] {world} ranks up, starting the tensor-parallel phase", file=sys.stderr, flush=True)
     # headline first: whatever happens to the side phases, its number exists by then
     tp = None if args.no_tp else spawn_phase(args, "tp", rank, local_rank, world)
     tp_first = None
-    if tp is not None:
+    if not args.no_tp:                           # every rank votes (ranks > 0 hold no result)
         # a failed tensor-parallel phase is tried once more with the engine's newer multi-rank
         # paths off.  Rank 0's verdict decides for everybody (only its child prints the numbers),
         # published through a key-value store next to the launcher's rendezvous port.
