@@ -172,6 +172,9 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
     t_init = time.perf_counter()
     eng = LLMEngine(cfg, spawn_workers=False)
     init_s = time.perf_counter() - t_init
+    if (os.environ.get("MINIVLLM_BENCH_INJECT_TP_FAILURE") == "1" and world > 1 and not replicas
+            and os.environ.get("MINIVLLM_TP_CONSERVATIVE") != "1"):
+        raise RuntimeError("injected failure of the first tensor-parallel attempt (test hook)")
     if replicas:
         runner = _ReplicaTimer() if dist.is_initialized() else _LocalTimer()
     else:
