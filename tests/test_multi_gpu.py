@@ -61,7 +61,10 @@ def _agreement(a, b):
     return same / total
 
 
-REL_TOL = 0.015          # TP=N against TP=1: same kernels, sums split over ranks (bf16 roundings)
+# TP=N against TP=1: same kernels, every row-parallel sum split over ranks and rounded to bf16 per
+# rank before it is reduced.  One bf16 step of the largest logit is 0.4-0.8 % of it; observed
+# maxima are 1.3-1.7 % (two to four steps), a mis-sharded weight gives errors of order 1.
+REL_TOL = 0.03
 
 
 def _teacher_forced_logits(cfg, steps=4):
