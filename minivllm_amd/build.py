@@ -45,6 +45,15 @@ def _run(cmd) -> None:
         raise RuntimeError(f"command failed: {' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
 
 
+def _file_flags(src: str) -> list:
+    """Extra compiler flags a source asks for: a line ``// hipcc-flags: ...`` among its first 40."""
+    with open(src) as f:
+        for _, line in zip(range(40), f):
+            if line.startswith("// hipcc-flags:"):
+                return line.split(":", 1)[1].split()
+    return []
+
+
 def build_hip(force: bool = False, verbose: bool = True) -> str:
     srcs = sorted(glob.glob(os.path.join(CSRC, "*.hip")))
     hdrs = sorted(glob.glob(os.path.join(CSRC, "*.h")))
@@ -60,7 +69,7 @@ def build_hip(force: bool = False, verbose: bool = True) -> str:
         o = os.path.join(BUILD, os.path.basename(s) + ".o")
         objs.append(o)
         if force or not _newer(o, [s] + hdrs):
-            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
+            jobs.append([hipcc] + flags + _file_flags(s) + ["-c", s, "-o", o])
     if jobs:
         if verbose:
             print(f"[build] compiling {len(jobs)} HIP source(s) for {ARCH}", flush=True)

@@ -68,7 +68,7 @@ struct PrefillArgs {
     // optional: q holds the raw projection and the kernel applies the per-head RMSNorm (weight
     // q_w, may be null) and the rotary embedding (fp32 table [position][D]: cos of the D/2
     // pairs, then sin) to its Q rows while it loads them; null cos_sin: q is used as it is
-    const int* positions;                      // [total tokens], indexed like q
+    const int* positions;                      // [total tokens], indexed like q; null: k_len - q_len + i
     const float* cos_sin;
     const uint16_t* q_w;
     float eps;
@@ -113,6 +113,17 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
 
     // ---- work decomposition: XCD-aware remap of the linear block id -----------------
     const int G = a.Hq / a.Hkv;
+    constexpr int kItemChunk = 4;
+    // the q-norm weights (D values, the same for every row and head) go through LDS: a copy in
+    // registers is 32 of them per lane at the prologue's peak, which is what decides whether that
+    // prologue fits without spills.  Requested here, stored and published (one barrier) right
+    // before the first use, when the load has long returned.
+    __shared__ u32x4_t s_qw[D / 8];
+    const bool has_qw = a.cos_sin != nullptr && a.q_w != nullptr;
+    bool qw_pending = has_qw;
+    u32x4_t qw_mine = {0u, 0u, 0u, 0u};
+    if (has_qw && threadIdx.x < D / 8)
+        qw_mine = *reinterpret_cast<const u32x4_t*>(a.q_w + 8 * threadIdx.x);
     int g, qti, kvh, b;
     if (a.items != nullptr) {
         // Work list: the real entries come first, the unused slots of the budget last, so the
@@ -120,7 +131,6 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
         // (blocks with equal id % 8 share an XCD): every XCD gets its share of the real work,
         // the G heads of a (slot, KV head) and the neighbouring pairs of a sequence - which read
         // the same K/V - stay on one L2.  n_items is a multiple of 8 kItemChunk (host).
-        constexpr int kItemChunk = 4;
         const int xcd = blockIdx.x & 7;
         int k = blockIdx.x >> 3;
         g = k % G;                         k /= G;
@@ -196,19 +206,10 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     // the first tile's DMA)
     // (an unconditional load from an address that is always valid: a conditional one would be
     // waited for where its branch ends, ahead of the first tile's requests)
-    const int my_rope_pos = *(a.cos_sin != nullptr ? a.positions + (q_start + my_q_c) : a.cu_q);
-    // the norm weights of the lane's 8-blocks, requested here for the same reason (256 bytes that
-    // every workgroup reads: cache hits); without a weight the Q row itself stands in, unused
-    u32x4_t qw_raw[KSTEPS];
-    {
-        const uint16_t* wp = a.q_w != nullptr
-            ? a.q_w : a.q + (long)(q_start + my_q_c) * a.q_stride_t + (long)head * a.q_stride_h;
-        if (a.cos_sin != nullptr) {
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s)
-                qw_raw[s] = *reinterpret_cast<const u32x4_t*>(wp + 16 * s + 8 * hh);
-        }
-    }
+    // (no positions given: a query's position is its place in the context - what a prefill step
+    // feeds - and the table row can be requested without waiting for anything)
+    const int my_rope_pos = a.positions == nullptr ? my_q_c + pos_off
+        : *(a.cos_sin != nullptr ? a.positions + (q_start + my_q_c) : a.cu_q);
     const int wave_min_pos = q0 + 32 * w + pos_off;
     const int wave_max_pos = min(q0 + 32 * w + 31, q_len - 1) + pos_off;
     const bool wave_live = q0 + 32 * w < q_len;
@@ -362,6 +363,11 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
     //      (e, e + D/2) of a row sit in one lane: fragments s and s + KSTEPS/2.  The table row
     //      was requested before the first tile's DMA; the arithmetic runs in that DMA's shadow.
     if (a.cos_sin != nullptr) {
+        if (qw_pending) {                                // uniform: the workgroup's first Q tile
+            if (threadIdx.x < D / 8) s_qw[threadIdx.x] = qw_mine;
+            __syncthreads();
+            qw_pending = false;
+        }
         // the rotary table row of the lane's query: requested here, after the first tile's DMA,
         // where few other values are live (requested earlier, the 64 registers were spilled one
         // load at a time, each behind its own vmcnt(0)); the sum of squares below covers part
@@ -398,8 +404,8 @@ __global__ __launch_bounds__(kThreads, 2) void flash_prefill_kernel(PrefillArgs 
             unpack8<CODE>(__builtin_bit_cast(u32x4_t, qfrag[s + KSTEPS / 2]), f2);
             if (a.q_w != nullptr) {
                 float w1[8], w2[8];
-                unpack8<CODE>(qw_raw[s], w1);
-                unpack8<CODE>(qw_raw[s + KSTEPS / 2], w2);
+                unpack8<CODE>(s_qw[2 * s + hh], w1);
+                unpack8<CODE>(s_qw[2 * (s + KSTEPS / 2) + hh], w2);
 #pragma unroll
                 for (int i = 0; i < 8; ++i) { f1[i] *= rstd * w1[i]; f2[i] *= rstd * w2[i]; }
             }
@@ -693,7 +699,6 @@ extern "C" int mvl_flash_attention_prefill(
         a.n_items = n_item_slots;
         a.total_wg = Hq * n_item_slots;
     }
-    if (cos_sin != nullptr && positions == nullptr) return -1;
     a.positions = positions; a.cos_sin = cos_sin; a.q_w = (const uint16_t*)q_w; a.eps = eps;
     // one uniform base per K/V tile: blocks of a multiple of 64 tokens, tile strides within 31 bits
     static const char* uni_env = getenv("MVL_PREFILL_UNI");

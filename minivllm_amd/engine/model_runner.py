@@ -905,6 +905,7 @@ class ModelRunner:
                     temperatures=v("temperatures").view(torch.float32),
                     step=v("misc"), context_lens=v("context_lens"),
                     prefill_items=v("prefill_items") if "prefill_items" in a else None,
+                    positions_in_context=True,
                     block_tables=v("block_tables").view(B, MB))
 
     def _fill_decode_host(self, b: Batch, padded_bs: int) -> None:
@@ -995,7 +996,8 @@ class ModelRunner:
                         num_decode_seqs=b.num_decode_seqs, num_prefill_tokens=b.num_prefill_tokens,
                         context_lens=t["context_lens"] if b.num_decode_seqs else None,
                         max_context_len=b.max_context_len, total_k_tokens=b.num_prefill_k_tokens,
-                        prefill_items=None if warmup else t["prefill_items"])
+                        prefill_items=None if warmup else t["prefill_items"],
+                        positions_in_context=True)
             tokens = self._forward_and_sample(t)
             logits = self._last_logits
         else:
@@ -1213,6 +1215,7 @@ class ModelRunner:
                     cu_seqlens_k=v("cu_seqlens_k", sb + 1),
                     temperatures=v("temperatures", sb).view(torch.float32), step=v("misc"),
                     prefill_items=v("prefill_items", hip.prefill_item_slots(tb, sb)),
+                    positions_in_context=True,
                     block_tables=v("block_tables", sb * MB).view(sb, MB))
 
     def _prefill_graph_key(self, b: Batch):
@@ -1239,7 +1242,7 @@ class ModelRunner:
                     max_seqlen_q=tb, max_seqlen_k=self.cfg.max_model_length,
                     slot_mapping=t["slot_mapping"], block_tables=t["block_tables"],
                     positions=t["positions"], num_seqs=sb, has_prefix=True,
-                    prefill_items=t["prefill_items"])
+                    prefill_items=t["prefill_items"], positions_in_context=True)
         out = self._forward_and_sample(t)
         reset_context()
         return out

@@ -109,7 +109,8 @@ class Attention(nn.Module):
                                                 ctx.cu_seqlens_k, ctx.block_tables, self.scale,
                                                 ctx.max_seqlen_q, max_seqlen_k=ctx.max_seqlen_k,
                                                 total_k=ctx.total_k_tokens, q_rope=q_rope,
-                                                work_items=ctx.prefill_items)
+                                                work_items=ctx.prefill_items,
+                                                positions_in_context=ctx.positions_in_context)
             else:
                 o = ops.flash_attention_prefill(q, k, v, ctx.cu_seqlens_q, self.scale,
                                                 ctx.max_seqlen_q, q_rope=q_rope)

@@ -99,13 +99,18 @@ def _into(out, res):
 
 def paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k, block_tables, scale,
                             max_seqlen_q=None, out=None, max_seqlen_k=None, total_k=None,
-                            q_rope=None, work_items=None):
+                            q_rope=None, work_items=None, positions_in_context=False):
     """``out``: optional [T, Hq, D] destination (a view into a larger buffer is fine).
+    ``positions_in_context``: the caller vouches that ``q_rope``'s positions are each query's
+    place in its context (k_len - q_len + i, what a prefill step feeds); the GPU kernel then
+    derives them instead of loading them (one dependent load less before its first tile).
     ``max_seqlen_k`` / ``total_k`` (longest context, sum of contexts) spare an fp8 cache's
     widening pass a device synchronisation and an oversized scratch buffer.  ``work_items``
     (GPU): the step's work list, which makes the launch shape independent of the lengths
     (``hip.prefill_work_items``)."""
     if _on_gpu(q):
+        if positions_in_context and q_rope is not None:
+            q_rope = (None,) + tuple(q_rope[1:])
         return _hip().paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k,
                                               block_tables, scale, max_seqlen_q, out=out,
                                               max_seqlen_k=max_seqlen_k, total_k=total_k,

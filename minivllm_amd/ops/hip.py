@@ -250,15 +250,18 @@ def _q_strides(q: torch.Tensor):
 
 
 def _q_rope_args(q: torch.Tensor, q_rope):
-    """``q_rope`` = (positions [T], cos_sin fp32 [max_pos, D], q_norm weight or None, eps): the
-    raw-Q transform the prefill kernel applies while loading its Q rows -> kernel arguments."""
+    """``q_rope`` = (positions [T] or None, cos_sin fp32 [max_pos, D], q_norm weight or None,
+    eps): the raw-Q transform the prefill kernel applies while loading its Q rows -> kernel
+    arguments.  Without positions the kernel takes a query's place in its context (the lengths
+    must then stay below the table's rows)."""
     if q_rope is None:
         return None, None, None, 0.0
     positions, cos_sin, q_weight, eps = q_rope
     if cos_sin.dtype != torch.float32 or cos_sin.shape[-1] != q.shape[-1] or not cos_sin.is_contiguous():
         raise TypeError("cos/sin table must be contiguous fp32 [positions, head_dim]")
-    positions = _i32(positions)
-    assert positions.numel() >= q.shape[0] and positions.is_contiguous()
+    if positions is not None:           # None: row i of a sequence sits at k_len - q_len + i
+        positions = _i32(positions)
+        assert positions.numel() >= q.shape[0] and positions.is_contiguous()
     if q_weight is not None:
         assert q_weight.dtype == q.dtype and q_weight.numel() == q.shape[-1] and q_weight.is_contiguous()
         assert q_weight.data_ptr() % 16 == 0

@@ -37,6 +37,9 @@ class Context:
     # GPU prefill: the attention kernel's work list (ops.hip.prefill_work_items), None = derive
     # the launch from max_seqlen_q
     prefill_items: Optional[torch.Tensor] = None
+    # prefill: every query's position is its place in its context (k_len - q_len + i); the GPU
+    # attention kernel then derives the rotary positions instead of loading them
+    positions_in_context: bool = False
 
 
 _CONTEXT = Context()

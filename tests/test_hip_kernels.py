@@ -1155,7 +1155,7 @@ def test_paged_prefill_from_a_work_list(hip, hq, hkv, d, bs):
     assert torch.equal(out, plain)
     # shuffled list: any order of the entries gives the same rows
     perm = torch.randperm(slots)
-    out2 = torch.empty_like(out)
+    out2 = torch.full_like(out, float("nan"))
     hip.paged_attention_prefill(q, kc, vc, cq, ck, tab, scale, max_seqlen_q=T, out=out2,
                                 work_items=items[perm.to(DEV)].contiguous())
     assert torch.equal(out2, out)
@@ -1168,6 +1168,10 @@ def test_paged_prefill_from_a_work_list(hip, hq, hkv, d, bs):
     b = hip.paged_attention_prefill(q, kc, vc, cq, ck, tab, scale, max_seqlen_q=T, q_rope=rope,
                                     work_items=items)
     assert torch.equal(a, b)
+    # positions derived from the lengths (k_len - q_len + i) instead of loaded
+    c = hip.paged_attention_prefill(q, kc, vc, cq, ck, tab, scale, max_seqlen_q=T,
+                                    q_rope=(None, cs, qw, eps), work_items=items)
+    assert torch.equal(c, b)
     close(b, ref.paged_attention_prefill(ref.apply_q_rope(q, rope), kc, vc, cq[:B + 1], ck[:B + 1],
                                          tables, scale), dtype)
     # captured once, replayed on other work

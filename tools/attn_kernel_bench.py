@@ -41,6 +41,14 @@ def main():
     ap.add_argument("--prefill", default="16x1024,4x4096,1x16384,1x32768")
     ap.add_argument("--decode", default="256x1024,64x4096,8x16384,1x32768")
     ap.add_argument("--kv-fp8", action="store_true", help="fp8 (e4m3) KV cache")
+    ap.add_argument("--work-list", action="store_true",
+                    help="prefill: the engine's form (work list in device memory, sized for the "
+                         "step budget)")
+    ap.add_argument("--implicit-positions", action="store_true",
+                    help="with --q-rope: no position array, the kernel uses k_len - q_len + i")
+    ap.add_argument("--q-rope", action="store_true",
+                    help="prefill: q-norm + RoPE of the Q rows inside the kernel (the engine's pure "
+                         "prefill steps)")
     a = ap.parse_args()
     eb = 1 if a.kv_fp8 else 2
     q8 = (lambda c: c.to(torch.float8_e4m3fn)) if a.kv_fp8 else (lambda c: c)
@@ -54,7 +62,21 @@ def main():
             q = torch.randn(B * S, hq, d, device="cuda", dtype=torch.bfloat16)
             cu = torch.arange(0, (B + 1) * S, S, device="cuda", dtype=torch.int32)
             bt = torch.arange(B * nblk, device="cuda", dtype=torch.int32).view(B, nblk)
-            t = timeit(lambda: hip.paged_attention_prefill(q, kc, vc, cu, cu, bt, scale, S), a.iters)
+            items = q_rope = None
+            if a.work_list:
+                import numpy as np
+                lens = np.full(B, S)
+                items = torch.from_numpy(hip.prefill_work_items(
+                    lens, lens, slots=hip.prefill_item_slots(B * S, max(B, 16)))).cuda()
+            if a.q_rope:
+                inv = 1.0 / (1e6 ** (torch.arange(0, d, 2, device="cuda").float() / d))
+                ang = torch.arange(S, device="cuda").float()[:, None] * inv[None]
+                q_rope = (None if a.implicit_positions else
+                          torch.arange(S, device="cuda", dtype=torch.int32).repeat(B),
+                          torch.cat([ang.cos(), ang.sin()], 1).contiguous(),
+                          torch.rand(d, device="cuda", dtype=torch.bfloat16) + 0.5, 1e-6)
+            t = timeit(lambda: hip.paged_attention_prefill(q, kc, vc, cu, cu, bt, scale, S,
+                                                           q_rope=q_rope, work_items=items), a.iters)
             fl = 4 * hq * d * B * S * (S + 1) / 2
             print(f"prefill B={B} S={S}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TFLOP/s (causal)", flush=True)
             del kc, vc, q
