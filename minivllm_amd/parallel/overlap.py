@@ -70,18 +70,16 @@ def row_parallel_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[to
     n = plan_chunks(T) if num_chunks is None else num_chunks
     if n <= 1 or x.dim() != 2 or pg.host_staged_collectives():
         return pg.tp_all_reduce(ops.linear(x, weight, bias))
-    out = torch.empty((T, weight.shape[0]), dtype=x.dtype, device=x.device)
-    works = []
+    works, parts = [], []
     bounds = chunk_bounds(T, n)
     for lo, hi in zip(bounds[:-1], bounds[1:]):
-        y = out[lo:hi]
-        # same entry point (and so the same tuned-shape lookup) as an unchunked projection
-        torch.addmm(bias, x[lo:hi], weight.t(), out=y) if bias is not None else \
-            torch.mm(x[lo:hi], weight.t(), out=y)
+        # same entry point (and so the same kernel choice) as an unchunked projection
+        y = ops.linear(x[lo:hi], weight, bias)
         works.append(dist.all_reduce(y, group=group, async_op=True))
+        parts.append(y)
     for w in works:
         w.wait()              # makes the compute stream wait for the collective's event
-    return out
+    return torch.cat(parts, 0)
 
 
 def row_parallel_linear_scatter(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
