@@ -37,12 +37,14 @@
 // Two optional epilogue duties take the (residual add + RMSNorm) passes out of a prefill layer
 // (reference: src/myvllm/layers/layernorm.py:19-22, src/myvllm/models/qwen3.py:191-195,216):
 //  * RES (o / down projections): out is the residual stream, updated in place,
-//    r = round(acc + bias + residual), and the sum of r^2 of every row is accumulated into ss_out
-//    [M] (fp32 atomics, one per wave and row), so that no separate pass has to read r again to
-//    normalise it;
-//  * row scale (qkv / gate_up projections, whose weights carry the norm's gamma): every output
-//    row is multiplied by rsqrt(ss_in[row] / K + eps) before bias / SwiGLU, which is the RMSNorm
-//    of the x row moved behind the GEMM:  (x rstd) . (W gamma)^T = rstd (x . (W gamma)^T).
+//    r = round(round(acc + bias) + residual);
+//  * RS, row scale (qkv / gate_up projections, whose weights carry the norm's gamma): every output
+//    row is multiplied by rsqrt(sum(x[row]^2) / K + eps) before bias / SwiGLU, which is the RMSNorm
+//    of the x row moved behind the GEMM:  (x rstd) . (W gamma)^T = rstd (x . (W gamma)^T).  The
+//    sums of squares come from the x fragments the waves hold for their MFMAs anyway (one v_dot2c
+//    per register, a quarter of a wave row's x rows per wave, issued where the wave otherwise
+//    only waits for the other wave row's MFMAs): no second pass over x, no buffer, nothing
+//    shared between workgroups.
 //
 // Call sites: the MLP's gate_up projection on prefill steps (the reference's
 // F.linear + SiluAndMul, src/myvllm/layers/linear.py:109, src/myvllm/layers/activation.py:8-16),
@@ -78,9 +80,7 @@ struct BigArgs {
     int up_off;                             // SwiGLU: row of W where the up projection starts
     int tiles_m, tiles_n, tiles, ktiles;
     int probe;                              // measurement only: 1 every tile loads tile 0's operands, 2 no stores
-    const float* ss_in;                     // row scale: per-row sum of squares of x (null: off)
-    float rs_eps, rs_inv_k;                 // rstd = rsqrt(ss_in[row] * rs_inv_k + rs_eps)
-    float* ss_out;                          // RES: per-row sum of squares of the new residual (zeroed by the caller)
+    float rs_eps, rs_inv_k;                 // RS: rstd = rsqrt(sum(x[row]^2) * rs_inv_k + rs_eps)
 };
 
 template <int N>
@@ -223,6 +223,28 @@ void big_gemm_kernel(BigArgs a) {
                 bf[ks][n] = __builtin_bit_cast(
                     vec8, *reinterpret_cast<const u32x4_t*>(base + n * 2048 + (b_off ^ (ks << 6))));
     };
+    // RS: sums of squares of the x rows.  The four waves of a wave row hold the same x fragments;
+    // wave wc sums x block wc, a quarter of the work each, and the waves exchange the results
+    // through LDS before the epilogue.  Which of its four fragment registers that block is
+    // depends on the wave, so the wave reads its block once more into registers of its own (two
+    // ds_read_b128 per half-tile; selecting among the MFMA operands instead costs a register
+    // copy per fragment).  ssq[top / bottom][k half]: the lane's k-chunks of row 16 wc + frow.
+    float ssq[2][2];
+    const int duty_off = a_off + wc * 2048;
+    auto sum_squares = [&](int bofs, auto j_c, int hb) {
+        if constexpr (RS) {
+            constexpr int J = decltype(j_c)::value;
+            const char* base = smem + bofs + J * kHalf;
+            u32x4_t v[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                v[ks] = *reinterpret_cast<const u32x4_t*>(base + (duty_off ^ (ks << 6)));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) ssq[hb][ks] = sumsq2<CODE>(v[ks][e], ssq[hb][ks]);
+        }
+    };
     auto mfma_quadrant = [&](auto q_c, vec8 (&bf)[2][2]) {
         constexpr int Q = decltype(q_c)::value;
 #pragma unroll
@@ -271,6 +293,7 @@ void big_gemm_kernel(BigArgs a) {
         MVL_STAMP(4);
         read_b(B, I2{}, br);
         stage(NB, I3{}, n1, k1);
+        sum_squares(B, I0{}, 0);             // the top x rows (A0: not overwritten before phase 3)
         if (!FIRST) big_wait_vmcnt<8>();
         MVL_STAMP(5);
         big_barrier();
@@ -291,6 +314,7 @@ void big_gemm_kernel(BigArgs a) {
         // phase 4: (bottom, left), no reads
         MVL_STAMP(12);
         stage(B, I1{}, n2, k2);
+        sum_squares(B, I3{}, 1);             // the bottom x rows (A1: safe until the next K-tile)
         if (!FIRST) big_wait_vmcnt<8>();
         MVL_STAMP(13);
         big_barrier();
@@ -312,11 +336,9 @@ void big_gemm_kernel(BigArgs a) {
     // straight from the accumulator layout cost 4x the write requests, which the L2 channels
     // could not absorb (0.6B qkv at 16384 rows: 127 us with them, 98 us without any store).
     char* const ep = smem + 2 * kBuf + wv * 4096;
-    // Operands of the epilogue that come from memory are requested BEFORE the wait that precedes
-    // it (the fragment registers are dead by then), so their latency is paid once per tile,
-    // together with the drain of the DMA queue: the row scales of the lane's 8 rows and, RES,
-    // the 16 residual chunks the lane will add to its 16 output chunks.
-    float rs[2][4];                          // [top / bottom][x block]
+    // RES: the 16 residual chunks the lane will add to its 16 output chunks are requested BEFORE
+    // the wait that precedes the epilogue (the fragment registers are dead by then), so their
+    // latency is paid once per tile, together with the drain of the DMA queue.
     u32x4_t resv[2][2][4];                   // [top / bottom][x block pair][store]
     auto out_voff = [&](int tm, int tn, int hb, int blk, int i) -> uint32_t {
         constexpr int LPRW = SWI ? 4 : 8, RPI = 64 / LPRW;
@@ -326,15 +348,6 @@ void big_gemm_kernel(BigArgs a) {
         return (uint32_t)row * (uint32_t)(a.o_stride * 2) + (uint32_t)(col_base * 2 + (lane % LPRW) * 16);
     };
     auto pre_epilogue = [&](int tm, int tn) {
-        if constexpr (RS) {
-#pragma unroll
-            for (int hb = 0; hb < 2; ++hb)
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int row = tm * 256 + hb * 128 + wr * 64 + 16 * m + frow;
-                    rs[hb][m] = a.ss_in[min(row, a.M - 1)];
-                }
-        }
         if constexpr (RES) {
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
@@ -344,6 +357,31 @@ void big_gemm_kernel(BigArgs a) {
                     for (int i = 0; i < 4; ++i)     // rows >= M: beyond out_bytes, read as 0
                         resv[hb][blk][i] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(
                             orsrc, (int)out_voff(tm, tn, hb, blk, i), 0, 0));
+        }
+    };
+    // RS: every wave needs the sums of all 64 top and 64 bottom rows of its wave row.  They pass
+    // through the first 512 bytes of the output block of the wave row's first wave, which is
+    // idle until the epilogue: write, barrier, read, barrier (both wave rows take both barriers,
+    // so the one-barrier distance between them is kept).
+    float rsv[2][4];
+    auto exchange_sums = [&]() {
+        if constexpr (RS) {
+            float* xch = reinterpret_cast<float*>(smem + 2 * kBuf + (wr * 4) * 4096);
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) {
+                float v = ssq[hb][0] + ssq[hb][1];           // a row's k-chunks: lanes frow + 16 fq
+                v += __shfl_xor(v, 16, 64);
+                v += __shfl_xor(v, 32, 64);
+                if (fq == 0) xch[(hb * 4 + wc) * 16 + frow] = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            big_barrier();
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) rsv[hb][m] = xch[(hb * 4 + m) * 16 + frow];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            big_barrier();
         }
     };
     auto epilogue = [&](int tm, int tn) {
@@ -378,11 +416,12 @@ void big_gemm_kernel(BigArgs a) {
                 }
             }
         const int orow = lane / LPRW, ochunk = lane % LPRW;
+        float rs[2][4];                                      // [top / bottom][x block]
         if constexpr (RS) {
 #pragma unroll
             for (int hb = 0; hb < 2; ++hb)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) rs[hb][m] = rsqrtf(rs[hb][m] * a.rs_inv_k + a.rs_eps);
+                for (int m = 0; m < 4; ++m) rs[hb][m] = rsqrtf(rsv[hb][m] * a.rs_inv_k + a.rs_eps);
         }
 #pragma unroll
         for (int hb = 0; hb < 2; ++hb) {                     // top / bottom rows of the wave
@@ -436,18 +475,9 @@ void big_gemm_kernel(BigArgs a) {
                         float p[8], q[8];
                         unpack8<CODE>(v, p);
                         unpack8<CODE>(resv[hb][blk][i], q);
-                        float ssq = 0.f;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            p[e] = DT::to_float(DT::from_float(p[e] + q[e]));
-                            ssq += p[e] * p[e];
-                        }
+                        for (int e = 0; e < 8; ++e) p[e] += q[e];
                         v = pack8<CODE>(p);
-                        // the 8 lanes of a row: sum over this wave's 64 columns, one atomic per row
-                        ssq += __shfl_xor(ssq, 1, 64);
-                        ssq += __shfl_xor(ssq, 2, 64);
-                        ssq += __shfl_xor(ssq, 4, 64);
-                        if (ochunk == 0 && row < a.M) atomicAdd(a.ss_out + row, ssq);
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, (int)voff, 0, 0);
                 }
@@ -461,6 +491,10 @@ void big_gemm_kernel(BigArgs a) {
             for (int n = 0; n < 2; ++n)
 #pragma unroll
                 for (int m = 0; m < 4; ++m) acc[q][n][m] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+        if constexpr (RS) {
+#pragma unroll
+            for (int hb = 0; hb < 2; ++hb) ssq[hb][0] = ssq[hb][1] = 0.f;
+        }
     };
 
     // ---- this workgroup's tiles
@@ -491,7 +525,8 @@ void big_gemm_kernel(BigArgs a) {
         // every request so far (up to A0 / B0 of the next tile's second K-tile) lands before
         // the stores are issued: loads and stores do not complete in a common order, so a
         // counted wait behind the stores would have to wait for all of them
-        if constexpr (RES || RS) pre_epilogue(tm, tn);
+        if constexpr (RES) pre_epilogue(tm, tn);
+        exchange_sums();
         big_wait_vmcnt<0>();
         epilogue(tm, tn);
         if (nid < 0) break;
@@ -530,15 +565,14 @@ int big_launch(BigArgs a, hipStream_t st) {
 // out[M, N_out] = x . W^T (+ bias)  [swiglu: W = [gate; up], N_out = N / 2].
 // K a multiple of 64 and >= 256; N a multiple of 256 (swiglu: N / 2 a multiple of 128); x rows
 // and out rows 16-byte aligned; x, W and out below 2 GiB each (32-bit buffer offsets).
-// ss_in (optional, [M] fp32): every output row is scaled by rsqrt(ss_in[row] / K + eps) before
-// bias / SwiGLU.  ss_out (optional, [M] fp32, zeroed by the caller; plain epilogue only): `out`
-// holds the residual stream on entry, out = round(round(x . W^T + bias) + out) in place, and
-// ss_out[row] += sum of out[row]^2.
+// row_scale: every output row is scaled by rsqrt(sum(x[row]^2) / K + eps) before bias / SwiGLU.
+// add_residual (plain epilogue only, not together with row_scale): `out` holds the residual
+// stream on entry, out = round(round(x . W^T + bias) + out) in place.
 extern "C" int mvl_big_gemm(const void* x, long x_stride, const void* w, const void* bias,
                             void* out, long o_stride, int M, int N, int K, int swiglu, int dtype,
-                            const float* ss_in, float eps, float* ss_out, void* stream) {
+                            int row_scale, float eps, int add_residual, void* stream) {
     if (M == 0) return 0;
-    if (ss_out != nullptr && swiglu) return -1;
+    if (add_residual && (swiglu || row_scale)) return -1;
     if (M < 0 || K % kBigBK != 0 || K < 4 * kBigBK || (dtype != 0 && dtype != 1)) return -1;
     if (swiglu ? (N % 2 != 0 || (N / 2) % 128 != 0) : (N % 256 != 0)) return -1;
     if (x_stride % 8 != 0 || o_stride % 8 != 0) return -1;
@@ -560,13 +594,11 @@ extern "C" int mvl_big_gemm(const void* x, long x_stride, const void* w, const v
     a.ktiles = K / kBigBK;
     static const char* probe_env = getenv("MVL_BIG_PROBE");
     a.probe = probe_env ? atoi(probe_env) : 0;
-    a.ss_in = ss_in; a.rs_eps = eps; a.rs_inv_k = 1.0f / (float)K; a.ss_out = ss_out;
+    a.rs_eps = eps; a.rs_inv_k = 1.0f / (float)K;
     auto st = (hipStream_t)stream;
-    if (ss_out != nullptr) {
-        if (ss_in != nullptr) return -1;             // one duty per projection
+    if (add_residual)
         return dtype == 0 ? big_launch<0, false, true>(a, st) : big_launch<1, false, true>(a, st);
-    }
-    if (ss_in != nullptr) {
+    if (row_scale) {
         if (dtype == 0) return swiglu ? big_launch<0, true, false, true>(a, st) : big_launch<0, false, false, true>(a, st);
         return swiglu ? big_launch<1, true, false, true>(a, st) : big_launch<1, false, false, true>(a, st);
     }

@@ -69,6 +69,20 @@ __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
     }
 }
 
+// c + sum of the squares of the two 16-bit values packed in w (one v_dot2c instruction)
+template <int CODE>
+__device__ __forceinline__ float sumsq2(uint32_t w, float c) {
+    if (CODE == 0) {
+        typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+        const bf16x2_t v = __builtin_bit_cast(bf16x2_t, w);
+        return __builtin_amdgcn_fdot2_f32_bf16(v, v, c, false);
+    } else {
+        typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
+        const f16x2_t v = __builtin_bit_cast(f16x2_t, w);
+        return __builtin_amdgcn_fdot2(v, v, c, false);
+    }
+}
+
 template <int CODE>
 __device__ __forceinline__ void unpack2(uint32_t w, float& lo, float& hi) {
     lo = DType<CODE>::to_float((uint16_t)(w & 0xffffu));

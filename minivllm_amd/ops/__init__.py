@@ -137,8 +137,8 @@ def linear(x, weight, bias=None, to_norm=False, residual=None):
     else), which lets a K-split mid-batch GEMM hand over its unsummed slices
     (``SplitKPartials``) for the norm kernel to sum.  ``residual`` (with ``to_norm``): the
     stream that norm will add the result to; a prefill-sized GPU projection may then add it in
-    its own epilogue and return ``ResidualSum`` (the stream, updated in place, and its row sums
-    of squares), which ``norm_linear`` / ``add_rms_norm`` / ``rms_norm`` accept in place of a
+    its own epilogue and return ``ResidualSum`` (the stream, updated in place, not yet
+    normalised), which ``norm_linear`` / ``add_rms_norm`` / ``rms_norm`` accept in place of a
     tensor."""
     if _on_gpu(x) and x.dim() == 2 and x.shape[0] <= 256:
         h = _hip()
@@ -193,10 +193,10 @@ def norm_linear(x, residual, gamma, eps, weight, bias=None, swiglu=False, gamma_
     was multiplied by ``gamma`` along its input dimension at load time (``gamma`` itself is all
     ones then); only such weights can take the one-kernel path, every other case runs the norm
     kernel followed by the projection."""
-    if isinstance(x, ResidualSum):                     # residual added + squares summed by the GEMM
+    if isinstance(x, ResidualSum):                     # the residual was added by the GEMM
         r = x.r
         if gamma_folded and _hip().big_gemm_ok(r, weight, swiglu):
-            return _hip().big_linear(r, weight, bias, swiglu, row_ss=x.ss, eps=eps), r
+            return _hip().big_linear(r, weight, bias, swiglu, row_scale=True, eps=eps), r
         h = rms_norm(r, gamma, eps)
         return (swiglu_linear(h, weight, bias) if swiglu else linear(h, weight, bias)), r
     if isinstance(x, PendingReduce):                   # row-parallel partial sum: reduce here

@@ -78,7 +78,7 @@ _mid = _sig("mvl_mid_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long
             _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_void)
 
 _big = _sig("mvl_big_gemm", _c_void, _c_long, _c_void, _c_void, _c_void, _c_long, _c_int, _c_int,
-            _c_int, _c_int, _c_int, _c_void, _c_float, _c_void, _c_void)
+            _c_int, _c_int, _c_int, _c_int, _c_float, _c_int, _c_void)
 
 _mid_eff_splits = _lib.mvl_mid_effective_splits
 _mid_eff_splits.argtypes = [_c_int, _c_int]
@@ -1013,12 +1013,13 @@ def tune_big_gemm(weights, swiglu: bool = False, rows=BIG_ROW_BUCKETS, margin: f
 
 def big_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None,
                swiglu: bool = False, out: Optional[torch.Tensor] = None,
-               row_ss: Optional[torch.Tensor] = None, eps: float = 0.0) -> torch.Tensor:
+               row_scale: bool = False, eps: float = 0.0) -> torch.Tensor:
     """``x @ weight.T (+ bias)``, or with ``swiglu`` ``silu(x @ Wg.T) * (x @ Wu.T)`` of the fused
     ``[Wg; Wu]`` weight, on the compute-bound 256 x 256-tile MFMA kernel (any row count; built
-    for prefill steps).  ``row_ss`` ([M] fp32: the sum of squares of every x row): the rows of
-    the product are multiplied by ``rsqrt(row_ss / K + eps)`` before bias / SwiGLU, i.e. ``x`` is
-    RMS-normalised behind the GEMM (for a ``weight`` that carries the norm's gamma)."""
+    for prefill steps).  ``row_scale``: the rows of the product are multiplied by
+    ``rsqrt(mean(x[row]^2) + eps)`` before bias / SwiGLU, i.e. ``x`` is RMS-normalised behind the
+    GEMM (for a ``weight`` that carries the norm's gamma); the kernel sums the squares from the
+    x fragments it loads anyway."""
     if not big_gemm_ok(x, weight, swiglu):
         raise ValueError(f"big_linear cannot take x {tuple(x.shape)} / weight {tuple(weight.shape)}")
     M, K = x.shape
@@ -1029,12 +1030,9 @@ def big_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tenso
     assert out.shape == (M, n_out) and out.stride(1) == 1 and out.stride(0) % 8 == 0 and out.dtype == x.dtype
     if bias is not None:
         assert bias.dtype == x.dtype and bias.numel() == N and bias.is_contiguous()
-    if row_ss is not None:
-        assert row_ss.dtype == torch.float32 and row_ss.numel() == M and row_ss.is_contiguous()
     _check(_big(x.data_ptr(), x.stride(0), weight.data_ptr(),
                 bias.data_ptr() if bias is not None else None, out.data_ptr(), out.stride(0),
-                M, N, K, int(swiglu), _dt(x), row_ss.data_ptr() if row_ss is not None else None,
-                float(eps), None, _stream()), "big_gemm")
+                M, N, K, int(swiglu), _dt(x), int(row_scale), float(eps), 0, _stream()), "big_gemm")
     return out
 
 
@@ -1051,18 +1049,17 @@ def big_resid_ok(x: torch.Tensor, weight: torch.Tensor, residual) -> bool:
 def big_linear_resid(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor],
                      residual: torch.Tensor) -> ResidualSum:
     """``residual <- round(round(x @ weight.T + bias) + residual)`` in place (the roundings of a
-    GEMM followed by the fused add + norm kernel) and, from the same epilogue, the sum of squares
-    of every new residual row: what a following RMSNorm needs, without a pass over the rows."""
+    GEMM followed by the fused add + norm kernel).  The RMSNorm that follows is left to the next
+    projection (``big_linear(row_scale=True)``), or to a plain norm kernel."""
     if not big_resid_ok(x, weight, residual):
         raise ValueError("big_linear_resid cannot take these operands")
     M, K = x.shape
     N = weight.shape[0]
-    ss = torch.zeros(M, dtype=torch.float32, device=x.device)
     _check(_big(x.data_ptr(), x.stride(0), weight.data_ptr(),
                 bias.data_ptr() if bias is not None else None, residual.data_ptr(),
-                residual.stride(0), M, N, K, 0, _dt(x), None, 0.0, ss.data_ptr(), _stream()),
+                residual.stride(0), M, N, K, 0, _dt(x), 0, 0.0, 1, _stream()),
            "big_gemm (residual epilogue)")
-    return ResidualSum(residual, ss)
+    return ResidualSum(residual)
 
 
 def big_gemm_resid_pays(x: torch.Tensor, weight: torch.Tensor, residual) -> bool:
@@ -1077,16 +1074,12 @@ def big_gemm_resid_pays(x: torch.Tensor, weight: torch.Tensor, residual) -> bool
 
 
 def tune_big_resid(prod_weights, cons_weights, cons_swiglu: bool, rows=BIG_ROW_BUCKETS,
-                   eps: float = 1e-6, margin: float = 0.96) -> dict:
+                   eps: float = 1e-6, margin: float = 0.98) -> dict:
     """For a projection that feeds (residual add + RMSNorm) and the projection behind that norm
     (o -> gate_up, down -> qkv; ``cons_weights`` carry the norm's gamma): time the chain as it runs
     unfused (best plain projection, add + norm kernel, best next projection) against the fused
     chain (residual epilogue, row-scaled next projection) at each row count and record the winner
-    under ``"resid"``.  Returns {rows: (unfused us, fused us, use fused)}.  The fused chain must
-    win clearly (4 %): measured in isolation the two are close on the shapes tried so far (the
-    residual epilogue re-reads the stream at the end of a kernel whose tiles all finish together,
-    and its row sums are contended atomics), and a chain that wins by a hair here has lost inside
-    the full step (profiles/r3_prefill_norm_folding.txt)."""
+    under ``"resid"``.  Returns {rows: (unfused us, fused us, use fused)}."""
     import torch.nn.functional as F
     from . import linear as _linear, swiglu_linear as _swiglu_linear
     pairs = list(zip(list(prod_weights)[:4], list(cons_weights)[:4]))
@@ -1107,7 +1100,7 @@ def tune_big_resid(prod_weights, cons_weights, cons_swiglu: bool, rows=BIG_ROW_B
 
         def fused(xx, pair):
             rs = big_linear_resid(xx, pair[0], None, resid)
-            return big_linear(rs.r, pair[1], None, cons_swiglu, row_ss=rs.ss, eps=eps)
+            return big_linear(rs.r, pair[1], None, cons_swiglu, row_scale=True, eps=eps)
         reps = max(1, min(8, int(2e11 / (2.0 * m * (n * k + nc * n)))))
         t_a = _graph_time_ms(unfused, x, pairs, reps)
         resid.zero_()

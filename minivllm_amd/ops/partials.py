@@ -10,9 +10,9 @@ That lets the work between the GEMM's accumulators and the normalised row be rea
   ``SplitKPartials``) whose all-reduce over the TP group is left to the consumer, which runs
   reduce + residual add + norm as one peer-to-peer kernel when it can.
 * ``ResidualSum``    - (one rank, prefill-sized) the projection's GEMM has already added the
-  residual stream in its epilogue and summed the squares of every new row; the next projection
-  applies the norm as a per-row factor behind ITS GEMM (its weights carry gamma), so the two
-  (residual add + RMSNorm) passes of a layer disappear.
+  residual stream in its epilogue; the next projection applies the norm as a per-row factor
+  behind ITS GEMM (its weights carry gamma), so the two (residual add + RMSNorm) passes of a
+  layer disappear.
 * ``ResidualShard``  - this rank's rows of the residual stream after a reduce-scatter shaped
   reduce + norm (the two-shot peer-to-peer kernel for decode-sized batches; RCCL reduce-scatter,
   norm on the rank's rows, all-gather for prefill-sized ones): only normalised rows are
@@ -67,16 +67,16 @@ class SplitKPartials:
 
 class ResidualSum:
     """The residual stream after a projection has been added to it inside that projection's
-    GEMM (``r`` [rows, hidden], updated in place by the kernel's epilogue), together with the
-    per-row sum of squares of ``r`` (``ss`` [rows] fp32) that the same epilogue accumulated:
-    ``rms_norm(r)[i] = r[i] * rsqrt(ss[i] / hidden + eps) * gamma``.  A consumer whose weights
-    carry ``gamma`` applies the row factor behind its own GEMM and no pass over ``r`` is needed
-    to normalise it; any other consumer just norms ``r``."""
+    GEMM (``r`` [rows, hidden], updated in place by the kernel's epilogue); its RMSNorm is still
+    to do.  A consumer whose weights carry ``gamma`` takes ``r`` as it is and applies
+    ``rsqrt(mean(r[i]^2) + eps)`` as a row factor behind its own GEMM, which sums the squares
+    from the rows it loads anyway, so no pass over ``r`` is needed to normalise it; any other
+    consumer just norms ``r``."""
 
-    __slots__ = ("r", "ss")
+    __slots__ = ("r",)
 
-    def __init__(self, r: torch.Tensor, ss: torch.Tensor):
-        self.r, self.ss = r, ss
+    def __init__(self, r: torch.Tensor):
+        self.r = r
 
     @property
     def shape(self):

@@ -1197,9 +1197,8 @@ def test_paged_prefill_from_a_work_list(hip, hq, hkv, d, bs):
 @pytest.mark.parametrize("M", [257, 1000, 4096])
 @pytest.mark.parametrize("N,K", [(1024, 2048), (1024, 3072), (4096, 4096), (4096, 12288), (5120, 3200)])
 def test_big_gemm_residual_epilogue(hip, dtype, M, N, K):
-    """o / down projection with the residual stream added in the epilogue (in place) and the
-    sum of squares of every new row accumulated by atomics: against GEMM, add and square sum in
-    fp32; rows beyond M untouched; with and without bias."""
+    """o / down projection with the residual stream added in the epilogue (in place): against
+    GEMM and add in fp32; rows beyond M untouched; with and without bias."""
     if K % 64:
         pytest.skip("K must be a multiple of 64")
     torch.manual_seed(61)
@@ -1214,8 +1213,6 @@ def test_big_gemm_residual_epilogue(hip, dtype, M, N, K):
     rs = hip.big_linear_resid(x, w, b, buf[:M])
     assert rs.r.data_ptr() == buf.data_ptr() and torch.equal(buf[M], guard)
     close(rs.r, want, dtype, 4)
-    ss_ref = rs.r.float().pow(2).sum(-1)                    # of the values actually stored
-    assert float(((rs.ss - ss_ref).abs() / ss_ref).max()) < 2e-3
     # the same call as the unfused pair of kernels would leave it
     r2 = res0.clone()
     hip.add_rms_norm(hip.big_linear(x, w, b), r2, torch.ones(N, device=DEV, dtype=dtype), 1e-6)
@@ -1224,7 +1221,7 @@ def test_big_gemm_residual_epilogue(hip, dtype, M, N, K):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("swiglu", [False, True])
-@pytest.mark.parametrize("M", [300, 2048])
+@pytest.mark.parametrize("M", [300, 2048, 5000])
 def test_big_gemm_row_scale_epilogue(hip, dtype, swiglu, M):
     """qkv / gate_up projection of an un-normalised x with the RMSNorm applied as a per-row factor
     behind the GEMM (weights carry gamma): against norm-then-GEMM in fp32 and against the
@@ -1236,7 +1233,7 @@ def test_big_gemm_row_scale_epilogue(hip, dtype, swiglu, M):
     w = (torch.randn(N, K, device=DEV) * 0.03).to(dtype)
     wg = (w.float() * gamma.float()[None]).to(dtype)          # gamma folded into the weights
     ss = x.float().pow(2).sum(-1)
-    got = hip.big_linear(x, wg, None, swiglu, row_ss=ss, eps=eps)
+    got = hip.big_linear(x, wg, None, swiglu, row_scale=True, eps=eps)
     xn = x.float() * torch.rsqrt(ss / K + eps)[:, None]
     y = xn @ wg.float().T
     want = torch.nn.functional.silu(y[:, :N // 2]) * y[:, N // 2:] if swiglu else y

@@ -28,7 +28,6 @@ W = {k: [(torch.randn(n, kk, device=dev) * 0.03).to(dt) for _ in range(4)] for k
 X = {k: torch.randn(M, kk, device=dev, dtype=dt) for k, (n, kk) in shapes.items()}
 ones = torch.ones(H, device=dev, dtype=dt)
 resid = torch.zeros(M, H, device=dev, dtype=dt)
-ss = torch.rand(M, device=dev) * H + 1.0
 
 
 def t(fn, x, ws, reps=2):
@@ -41,15 +40,14 @@ for k in shapes:
     lib = (lambda xx, w: hip.silu_and_mul(F.linear(xx, w))) if sw else (lambda xx, w: F.linear(xx, w))
     row = {"lib": t(lib, X[k], W[k]), "big": t(lambda xx, w: hip.big_linear(xx, w, None, sw), X[k], W[k])}
     if k in ("qkv", "gate_up"):
-        row["big+rowscale"] = t(lambda xx, w: hip.big_linear(xx, w, None, sw, row_ss=ss, eps=1e-6), X[k], W[k])
+        row["big+rowscale"] = t(lambda xx, w: hip.big_linear(xx, w, None, sw, row_scale=True, eps=1e-6), X[k], W[k])
     else:
         row["big+resid"] = t(lambda xx, w: hip.big_linear_resid(xx, w, None, resid), X[k], W[k])
     n, kk = shapes[k]
     fl = 2.0 * M * n * kk
     print(f"  {k:8s} [{n} x {kk}] " + "  ".join(f"{nm} {v:7.1f} us ({fl / v / 1e9:5.2f} PF/s)" for nm, v in row.items()), flush=True)
 xx = torch.randn(M, H, device=dev, dtype=dt)
-print(f"  add_rms_norm {t(lambda x_, w: hip.add_rms_norm(x_, resid, ones, 1e-6), xx, [None]):7.1f} us   "
-      f"zeros {t(lambda x_, w: torch.zeros(M, device=dev), xx, [None]):5.1f} us")
+print(f"  add_rms_norm {t(lambda x_, w: hip.add_rms_norm(x_, resid, ones, 1e-6), xx, [None]):7.1f} us")
 for prod, cons, sw in (("o", "gate_up", True), ("down", "qkv", False)):
     r = hip.tune_big_resid(W[prod], W[cons], sw, rows=[M])
     print(f"  chain {prod} -> norm -> {cons}: unfused {r[M][0]} us, fused {r[M][1]} us", flush=True)
