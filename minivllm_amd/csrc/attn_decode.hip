@@ -22,6 +22,13 @@
 //    O^T = V^T . P^T, and V^T fragments come from ds_read_b64_tr_b16 (hardware transpose);
 //  * the grid does not depend on context lengths (rows with length 0 exit immediately), so
 //    a launch can be captured in a hipGraph and replayed for any batch content;
+//  * FUSE (16-bit cache): q, and the new token's k and v, arrive as projected.  The kernel applies
+//    the per-head RMSNorm and the rotary embedding to its query heads while it loads them, and
+//    the wave that owns the context's last tile does the same for the new key, writes key and
+//    value into their cache slot and patches them into its LDS image of that tile (the slot's
+//    old content is what the tile load fetched) - which is the work of the separate
+//    norm + rotate + store kernel (reference: src/myvllm/models/qwen3.py:97-116,
+//    src/myvllm/layers/attention.py:63-108) without its launch and its pass over q;
 //  * KV8: the cache holds OCP fp8 (e4m3) instead of 16-bit values.  A tile is then half the
 //    bytes (the kernel is bound by exactly those bytes); the registers -> LDS staging step
 //    widens it to the query's 16-bit type, so the LDS image and both MFMA products are the same
@@ -65,14 +72,23 @@ __device__ __forceinline__ int dec_tile_off(int row, int ch) {
     return row * (CPR * 16) + ((ch ^ x) << 4);
 }
 
-template <int CODE, int D, bool KV8>
-__global__ __launch_bounds__(256) void paged_decode_kernel(
+// the raw projections and what turns them into queries / keys (FUSE only)
+struct DecodeFuse {
+    const uint16_t* k_new; const uint16_t* v_new;   // [B, Hkv, D] with q's batch stride
+    const float* cos_sin;                           // fp32 [positions][D]: cos of the D/2 pairs, then sin
+    const uint16_t* q_w; const uint16_t* k_w;       // norm weights [D], null: no norm
+    float eps;
+};
+
+template <int CODE, int D, bool KV8, bool FUSE = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void paged_decode_kernel(
         const uint16_t* __restrict__ q, long q_stride_b, long q_stride_h,
-        const char* __restrict__ k_cache, const char* __restrict__ v_cache,
+        char* __restrict__ k_cache, char* __restrict__ v_cache,
         long cs_b, long cs_t, long cs_h, const int* __restrict__ block_tables, int bt_stride,
         const int* __restrict__ context_lens, uint16_t* __restrict__ out, long o_stride_b,
         long o_stride_h, float* part_acc, float* part_ml, int* tickets,
-        float scale_log2, int Hq, int Hkv, int bs_log2, int nsplit) {
+        float scale_log2, int Hq, int Hkv, int bs_log2, int nsplit, DecodeFuse fu) {
+    static_assert(!(FUSE && KV8), "the fused form writes a 16-bit cache");
     using DT = DType<CODE>;
     using vec8 = typename DT::vec8;
     constexpr int CPR = D / 8;                 // 16-byte chunks per row of the LDS image
@@ -122,6 +138,42 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
     }
 
     const int* bt = block_tables + (long)b * bt_stride;
+    // ---- FUSE: norm + rotary embedding of the query heads (position = L - 1, the new token's),
+    //      and in the wave that owns the last tile the new key / value.  A lane holds elements
+    //      32 s + 8 q4 .. +7 of its row; the pair (e, e + D/2) is fragments s and s + KSTEPS/2.
+    //      What it needs from memory is requested here, ahead of the first K/V tile; the
+    //      arithmetic follows those requests and runs while the tile is on its way.
+    constexpr int HS = KSTEPS / 2;
+    const int tile_last = total_tiles - 1;
+    const bool own = FUSE && L > 0 && tile_last >= t0 && tile_last < t1 && ((tile_last - t0) % kWaves) == w;
+    u32x4_t knew[KSTEPS], vnew[KSTEPS];
+    f32x4_t cs_raw[FUSE ? HS : 1][4];                        // [s][cos lo, cos hi, sin lo, sin hi]
+    u32x4_t qw_raw[FUSE ? KSTEPS : 1], kw_raw[FUSE ? KSTEPS : 1];
+    if constexpr (FUSE) {
+        if (fu.q_w != nullptr) {
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s)
+                qw_raw[s] = *reinterpret_cast<const u32x4_t*>(fu.q_w + 32 * s + 8 * q4);
+        }
+        const float* cs = fu.cos_sin + (long)max(L - 1, 0) * D;
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+            cs_raw[s][0] = *reinterpret_cast<const f32x4_t*>(cs + 32 * s + 8 * q4);
+            cs_raw[s][1] = *reinterpret_cast<const f32x4_t*>(cs + 32 * s + 8 * q4 + 4);
+            cs_raw[s][2] = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 32 * s + 8 * q4);
+            cs_raw[s][3] = *reinterpret_cast<const f32x4_t*>(cs + D / 2 + 32 * s + 8 * q4 + 4);
+        }
+        if (own) {                                           // wave-uniform
+            const long at = b * q_stride_b + (long)kvh * D + 8 * q4;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                knew[s] = *reinterpret_cast<const u32x4_t*>(fu.k_new + at + 32 * s);
+                vnew[s] = *reinterpret_cast<const u32x4_t*>(fu.v_new + at + 32 * s);
+                if (fu.k_w != nullptr)
+                    kw_raw[s] = *reinterpret_cast<const u32x4_t*>(fu.k_w + 32 * s + 8 * q4);
+            }
+        }
+    }
     // Address arithmetic in 32 bits wherever the launcher's range checks allow: only the block
     // base is a 64-bit product (with the fp8 cache the waves issue instructions nearly half of
     // their cycles, and the addresses of a tile were a quarter of them).
@@ -188,6 +240,53 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
         if (tile + kWaves < t1) load_block_ids(tile + kWaves, ids_next);
     }
 
+    // same arithmetic as the stand-alone kernel: x * (rstd * w), rotate in fp32, round once
+        auto transform = [&](auto& f, const uint16_t* wgt, bool is_q) {   // generic: FUSE only
+        float x[KSTEPS][8];
+        float ss = 0.f;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            unpack8<CODE>(f[s], x[s]);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) ss += x[s][i] * x[s][i];
+        }
+        ss += __shfl_xor(ss, 16, 64);
+        ss += __shfl_xor(ss, 32, 64);
+        if (wgt != nullptr) {
+            const float rstd = rsqrtf(ss / (float)D + fu.eps);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                float wv[8];
+                unpack8<CODE>(is_q ? qw_raw[s] : kw_raw[s], wv);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) x[s][i] *= rstd * wv[i];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < HS; ++s) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float c = cs_raw[s][i >> 2][i & 3], sn = cs_raw[s][2 + (i >> 2)][i & 3];
+                const float x1 = x[s][i], x2 = x[s + HS][i];
+                x[s][i] = x1 * c - x2 * sn;
+                x[s + HS][i] = x1 * sn + x2 * c;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) f[s] = pack8<CODE>(x[s]);
+    };
+    if constexpr (FUSE) {
+        {
+            u32x4_t qraw[KSTEPS];
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) qraw[s] = __builtin_bit_cast(u32x4_t, qfrag[s]);
+            transform(qraw, fu.q_w, true);
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) qfrag[s] = __builtin_bit_cast(vec8, qraw[s]);
+        }
+        if (own) transform(knew, fu.k_w, false);
+    }
+
     for (; tile < t1; tile += kWaves) {
         // registers -> wave-private LDS image (swizzled); same-wave DS ops stay in order
 #pragma unroll
@@ -206,6 +305,38 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
                 const int o = dec_tile_off<CPR>(st_row[i], st_ch[i]);
                 *reinterpret_cast<u32x4_t*>(k_lds + o) = kreg[i];
                 *reinterpret_cast<u32x4_t*>(v_lds + o) = vreg[i];
+            }
+        }
+        if constexpr (FUSE) {
+            if (own && tile == tile_last) {
+                // The new token's slot has not been written yet: row (L - 1) % 32 of the image
+                // and the rows behind it (the loads of a tile's tail repeat token L - 1) hold
+                // whatever the slot held.  All of them get the new key / value (the tail rows
+                // are masked out of the softmax, but their V rows must be finite); the first
+                // head group's lanes c16 == 0 also write the slot itself.
+                const int r = (L - 1) & (kTile - 1);
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int row = r + c16 + 16 * half;
+                    if (row < kTile) {
+#pragma unroll
+                        for (int s = 0; s < KSTEPS; ++s) {
+                            const int o = dec_tile_off<CPR>(row, 4 * s + q4);
+                            *reinterpret_cast<u32x4_t*>(k_lds + o) = knew[s];
+                            *reinterpret_cast<u32x4_t*>(v_lds + o) = vnew[s];
+                        }
+                    }
+                }
+                if (c16 == 0 && hg == 0) {
+                    const unsigned tok = (unsigned)(L - 1);
+                    const unsigned long off = (unsigned long)(unsigned)bt[tok >> bs_log2] * cs_b_bytes
+                        + __umul24(tok & (unsigned)bs_mask, cs_t_bytes) + head_off_bytes + q4 * 16;
+#pragma unroll
+                    for (int s = 0; s < KSTEPS; ++s) {
+                        *reinterpret_cast<u32x4_t*>(k_cache + off + 64 * s) = knew[s];
+                        *reinterpret_cast<u32x4_t*>(v_cache + off + 64 * s) = vnew[s];
+                    }
+                }
             }
         }
         if (tile + kWaves < t1) {
@@ -363,10 +494,10 @@ __global__ __launch_bounds__(256) void paged_decode_kernel(
 }
 
 template <int CODE, int D, bool KV8>
-int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void* vc, long csb,
+int launch_decode(const void* q, long qsb, long qsh, void* kc, void* vc, long csb,
                   long cst, long csh, const int* bt, int bt_stride, const int* ctx, void* out,
                   long osb, long osh, float* part_acc, float* part_ml, int* tickets, float scale,
-                  int B, int Hq, int Hkv, int block_size, int nsplit, hipStream_t st) {
+                  int B, int Hq, int Hkv, int block_size, int nsplit, DecodeFuse fu, hipStream_t st) {
     int bs_log2 = 0;
     while ((1 << bs_log2) < block_size) ++bs_log2;
     // the kernel forms in-block byte offsets in 32 bits (token stride through a 24-bit multiply)
@@ -378,10 +509,20 @@ int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void*
     const int ngrp = (G + 15) / 16;
     dim3 grid(nsplit, Hkv * ngrp, B);
     const size_t lds = (size_t)kWaves * 2 * kTile * D * 2;
+    if constexpr (!KV8) {
+        if (fu.k_new != nullptr) {
+            paged_decode_kernel<CODE, D, KV8, true><<<grid, 256, lds, st>>>(
+                (const uint16_t*)q, qsb, qsh, (char*)kc, (char*)vc, csb, cst, csh, bt,
+                bt_stride, ctx, (uint16_t*)out, osb, osh, part_acc, part_ml, tickets, scale * kLog2e,
+                Hq, Hkv, bs_log2, nsplit, fu);
+            return MVL_CHECK_LAUNCH();
+        }
+    }
+    if (fu.k_new != nullptr) return -1;
     paged_decode_kernel<CODE, D, KV8><<<grid, 256, lds, st>>>(
-        (const uint16_t*)q, qsb, qsh, (const char*)kc, (const char*)vc, csb, cst, csh, bt,
+        (const uint16_t*)q, qsb, qsh, (char*)kc, (char*)vc, csb, cst, csh, bt,
         bt_stride, ctx, (uint16_t*)out, osb, osh, part_acc, part_ml, tickets, scale * kLog2e, Hq,
-        Hkv, bs_log2, nsplit);
+        Hkv, bs_log2, nsplit, fu);
     return MVL_CHECK_LAUNCH();
 }
 
@@ -393,13 +534,22 @@ int launch_decode(const void* q, long qsb, long qsh, const void* kc, const void*
 // ints that are zero at the first launch and shared with no launch that may run at the same
 // time (the kernel leaves them zero).  kv_fp8 != 0: the caches hold OCP fp8 e4m3 bytes instead
 // of values of the query's dtype.
+// k_new != null (16-bit cache only): q, k_new [B, Hkv, D] and v_new (q's batch stride) are the raw
+// projections of the step's new tokens, whose positions are context_lens - 1; the kernel norms
+// (q_w / k_w, each may be null) and rotates (cos_sin) q and k_new itself and writes k / v into
+// the caches at those positions before the step's attention reads them.
 extern "C" int mvl_paged_attention_decode(
-        const void* q, long q_stride_b, long q_stride_h, const void* k_cache, const void* v_cache,
+        const void* q, long q_stride_b, long q_stride_h, void* k_cache, void* v_cache,
         long cs_b, long cs_t, long cs_h, const int* block_tables, int bt_stride,
         const int* context_lens, void* out, long o_stride_b, long o_stride_h, float* part_acc,
         float* part_ml, int* tickets, float scale, int B, int Hq, int Hkv, int D, int block_size,
-        int nsplit, int dtype, int kv_fp8, void* stream) {
+        int nsplit, int dtype, int kv_fp8, const void* k_new, const void* v_new,
+        const float* cos_sin, const void* q_w, const void* k_w, float eps, void* stream) {
     if (B == 0) return 0;
+    if (k_new != nullptr && (v_new == nullptr || cos_sin == nullptr || kv_fp8)) return -1;
+    DecodeFuse fu;
+    fu.k_new = (const uint16_t*)k_new; fu.v_new = (const uint16_t*)v_new; fu.cos_sin = cos_sin;
+    fu.q_w = (const uint16_t*)q_w; fu.k_w = (const uint16_t*)k_w; fu.eps = eps;
     if ((D != 64 && D != 128) || Hq % Hkv != 0 || (block_size & (block_size - 1)) || nsplit < 1 ||
         nsplit > 64)
         return -1;
@@ -409,7 +559,7 @@ extern "C" int mvl_paged_attention_decode(
     return launch_decode<CODE, DD, K8>(q, q_stride_b, q_stride_h, k_cache, v_cache, cs_b, cs_t,    \
                                        cs_h, block_tables, bt_stride, context_lens, out,           \
                                        o_stride_b, o_stride_h, part_acc, part_ml, tickets, scale,  \
-                                       B, Hq, Hkv, block_size, nsplit, st)
+                                       B, Hq, Hkv, block_size, nsplit, fu, st)
     if (kv_fp8) {
         if (dtype == 0) { if (D == 128) MVL_DEC(0, 128, true); else MVL_DEC(0, 64, true); }
         else            { if (D == 128) MVL_DEC(1, 128, true); else MVL_DEC(1, 64, true); }

@@ -798,7 +798,7 @@ class ModelRunner:
         t = self._decode_tensors(B)
         set_context(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
                     block_tables=t["block_tables"], positions=t["positions"],
-                    max_context_len=b.max_context_len, num_seqs=B)
+                    max_context_len=b.max_context_len, num_seqs=B, positions_in_context=True)
         tokens = self._forward_and_sample(t)
         reset_context()
         return tokens
@@ -1016,7 +1016,8 @@ class ModelRunner:
                 t = self._decode_tensors(B)
                 set_context(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
                             block_tables=t["block_tables"], positions=t["positions"],
-                            max_context_len=b.max_context_len, num_seqs=B)
+                            max_context_len=b.max_context_len, num_seqs=B,
+                            positions_in_context=True)
                 tokens = self._forward_and_sample(t)
                 logits = self._last_logits
         reset_context()
@@ -1182,7 +1183,8 @@ class ModelRunner:
             def step():
                 set_context(False, slot_mapping=t["slot_mapping"], context_lens=t["context_lens"],
                             block_tables=t["block_tables"], positions=t["positions"],
-                            max_context_len=self.cfg.max_model_length, num_seqs=bs)
+                            max_context_len=self.cfg.max_model_length, num_seqs=bs,
+                            positions_in_context=True)
                 out = self._forward_and_sample(t)
                 reset_context()
                 return out

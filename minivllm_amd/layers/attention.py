@@ -61,6 +61,8 @@ def paged_attention_decode(query: torch.Tensor, k_cache: torch.Tensor, v_cache: 
 # --------------------------------------------------------------------- layer
 # MINIVLLM_NO_Q_FUSE=1: q-norm + RoPE of the Q rows stay in the store kernel (for A/B timing)
 _FUSE_Q_ROPE = os.environ.get("MINIVLLM_NO_Q_FUSE", "0") != "1"
+# MINIVLLM_NO_DECODE_FUSE=1: decode steps keep the stand-alone norm + rotate + store kernel
+_FUSE_DECODE_STORE = os.environ.get("MINIVLLM_NO_DECODE_FUSE", "0") != "1"
 
 
 class Attention(nn.Module):
@@ -83,6 +85,14 @@ class Attention(nn.Module):
         through the decode kernel, which expects finished queries."""
         return bool(_FUSE_Q_ROPE and ctx.is_prefill and not ctx.num_decode_seqs and q.is_cuda)
 
+    def fuses_decode_store(self, ctx, qkv: torch.Tensor) -> bool:
+        """True for the steps whose attention takes the raw q / k / v projections and does the
+        norm, the rotation and the cache write itself (``new_kv``): pure decode steps on the GPU
+        with a 16-bit cache whose positions are ``context_lens - 1`` (the engine's are)."""
+        return bool(_FUSE_DECODE_STORE and not ctx.is_prefill and qkv.is_cuda
+                    and ctx.positions_in_context and self.k_cache is not None
+                    and self.k_cache.dtype != torch.float8_e4m3fn and self.head_dim in (64, 128))
+
     def reads_k_from_cache(self, ctx) -> bool:
         """True for prefill steps whose attention goes through the block table of a 16-bit cache
         (the freshly projected ``k`` / ``v`` arguments of ``forward`` are then never read)."""
@@ -90,13 +100,16 @@ class Attention(nn.Module):
                     and ctx.slot_mapping is not None and self.k_cache.dtype != torch.float8_e4m3fn)
 
     def forward(self, q: torch.Tensor, k: Optional[torch.Tensor] = None,
-                v: Optional[torch.Tensor] = None, q_rope=None) -> torch.Tensor:
+                v: Optional[torch.Tensor] = None, q_rope=None, new_kv=None) -> torch.Tensor:
         """q [T,Hq,D] (rows may be strided); k/v [T,Hkv,D] are only read when no cache
         is attached.  ``q_rope`` (prefill steps only): q holds the raw projection, see
-        ``ops.flash_attention_prefill``.  Returns [T, Hq*D]."""
+        ``ops.flash_attention_prefill``.  ``new_kv`` = (cos_sin, q_norm weight, k_norm weight,
+        eps) (decode steps only, ``fuses_decode_store``): q, k and v are raw projections, see
+        ``ops.paged_attention_decode``.  Returns [T, Hq*D]."""
         ctx = get_context()
         T = q.shape[0]
         assert q_rope is None or self.fuses_q_rope(ctx, q)
+        assert new_kv is None or self.fuses_decode_store(ctx, q)
         if ctx.is_prefill and ctx.num_decode_seqs:
             return self._mixed(q, ctx)
         if ctx.is_prefill:
@@ -118,7 +131,8 @@ class Attention(nn.Module):
             if self.k_cache is None:
                 raise RuntimeError("decode needs an allocated KV cache")
             o = ops.paged_attention_decode(q, self.k_cache, self.v_cache, ctx.block_tables,
-                                           ctx.context_lens, self.scale, ctx.max_context_len)
+                                           ctx.context_lens, self.scale, ctx.max_context_len,
+                                           new_kv=(k, v) + tuple(new_kv) if new_kv is not None else None)
         return o.reshape(T, self.num_heads * self.head_dim)
 
     def _mixed(self, q: torch.Tensor, ctx) -> torch.Tensor:

@@ -73,6 +73,17 @@ class Qwen3Attention(nn.Module):
         ctx = get_context()
         cos_sin = self._rope[0].cos_sin_cache
         q_weight = self.q_norm.weight if self.use_qk_norm else None
+        if self.attn.fuses_decode_store(ctx, qkv):
+            # decode steps on the GPU: the attention kernel norms and rotates q and the new k
+            # and writes the new k / v into the cache itself
+            hq, hkv, d = self.num_heads, self.num_kv_heads, self.head_dim
+            T = qkv.shape[0]
+            q = qkv[:, :hq * d].view(T, hq, d)
+            k = qkv[:, hq * d:(hq + hkv) * d].view(T, hkv, d)
+            v = qkv[:, (hq + hkv) * d:].view(T, hkv, d)
+            o = self.attn(q, k, v, new_kv=(cos_sin, q_weight,
+                                           self.k_norm.weight if self.use_qk_norm else None, self.eps))
+            return self.o_proj(o, defer_reduce=defer_reduce, residual=residual)
         # pure prefill steps on the GPU: the store kernel handles K and V only and the
         # attention kernel norms and rotates its Q rows while loading them
         fuse = self.attn.fuses_q_rope(ctx, qkv)

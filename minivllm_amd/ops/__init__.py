@@ -121,10 +121,14 @@ def paged_attention_prefill(q, k_cache, v_cache, cu_seqlens_q, cu_seqlens_k, blo
 
 
 def paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens, scale,
-                           max_context_len=None, out=None):
+                           max_context_len=None, out=None, new_kv=None):
+    """``new_kv`` (GPU, 16-bit caches; see ``hip.paged_attention_decode``): q and the new
+    tokens' k / v are raw projections; the kernel norms, rotates and stores them itself."""
     if _on_gpu(q):
         return _hip().paged_attention_decode(q, k_cache, v_cache, block_tables, context_lens,
-                                             scale, max_context_len, out=out)
+                                             scale, max_context_len, out=out, new_kv=new_kv)
+    if new_kv is not None:
+        raise ValueError("new_kv is a form of the GPU kernel")
     return _into(out, torch_ref.paged_attention_decode(q, k_cache, v_cache, block_tables,
                                                        context_lens, scale))
 

@@ -55,7 +55,7 @@ _sample_filtered = _sig("mvl_sample_filtered", _c_void, _c_long, _c_int, _c_int,
 _decode = _sig("mvl_paged_attention_decode", _c_void, _c_long, _c_long, _c_void, _c_void, _c_long,
                _c_long, _c_long, _c_void, _c_int, _c_void, _c_void, _c_long, _c_long, _c_void,
                _c_void, _c_void, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
-               _c_int, _c_void)
+               _c_int, _c_void, _c_void, _c_void, _c_void, _c_void, _c_float, _c_void)
 _prefill = _sig("mvl_flash_attention_prefill", _c_void, _c_long, _c_long, _c_void, _c_void,
                 _c_long, _c_long, _c_long, _c_void, _c_long, _c_long, _c_void, _c_void, _c_void,
                 _c_int, _c_int, _c_float, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int,
@@ -432,9 +432,15 @@ def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torc
                            max_context_len: Optional[int] = None,
                            num_splits: Optional[int] = None,
                            out: Optional[torch.Tensor] = None,
-                           tickets: Optional[torch.Tensor] = None) -> torch.Tensor:
+                           tickets: Optional[torch.Tensor] = None,
+                           new_kv=None) -> torch.Tensor:
     """``tickets``: zeroed int32 scratch of B * Hkv * ceil(G / 16) words for callers that run
-    decode launches concurrently on several streams of one device (each stream its own)."""
+    decode launches concurrently on several streams of one device (each stream its own).
+    ``new_kv`` = (k [B, Hkv, D], v [B, Hkv, D], cos_sin fp32 [positions, D], q_norm weight or
+    None, k_norm weight or None, eps), 16-bit caches only: ``q``, ``k`` and ``v`` are the raw
+    projections of the step's new tokens (views of one qkv tensor), whose positions are
+    ``context_lens - 1``.  The kernel norms and rotates q and k itself and writes k / v into the
+    caches at those positions: the stand-alone norm + rotate + store kernel is not needed."""
     B, hq, d = q.shape
     hkv = k_cache.shape[2]
     bt, ctx = _i32(block_tables), _i32(context_lens)
@@ -456,10 +462,29 @@ def paged_attention_decode(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torc
         pa, pm, tk = part_acc.data_ptr(), part_ml.data_ptr(), tickets.data_ptr()
     else:
         pa = pm = tk = None
+    fuse = (None, None, None, None, None, 0.0)
+    if new_kv is not None:
+        k_new, v_new, cos_sin, q_w, k_w, eps = new_kv
+        if _kv_fp8(k_cache):
+            raise ValueError("the fused decode form writes 16-bit caches only")
+        if cos_sin.dtype != torch.float32 or cos_sin.shape[-1] != d or not cos_sin.is_contiguous():
+            raise TypeError("cos/sin table must be contiguous fp32 [positions, head_dim]")
+        for t in (k_new, v_new):
+            assert t.shape == (B, hkv, d) and t.dtype == q.dtype and t.stride(2) == 1 \
+                and t.stride(1) == d and (B == 1 or t.stride(0) == qs_b) and t.data_ptr() % 16 == 0
+        assert q.data_ptr() % 16 == 0 and qs_b % 8 == 0 and qs_h % 8 == 0
+        assert k_cache.data_ptr() % 16 == 0 and v_cache.data_ptr() % 16 == 0 \
+            and sb % 8 == 0 and st % 8 == 0 and sh % 8 == 0
+        for w_ in (q_w, k_w):
+            assert w_ is None or (w_.dtype == q.dtype and w_.numel() == d and w_.is_contiguous()
+                                  and w_.data_ptr() % 16 == 0)
+        fuse = (k_new.data_ptr(), v_new.data_ptr(), cos_sin.data_ptr(),
+                q_w.data_ptr() if q_w is not None else None,
+                k_w.data_ptr() if k_w is not None else None, float(eps))
     _check(_decode(q.data_ptr(), qs_b, qs_h, k_cache.data_ptr(), v_cache.data_ptr(), sb, st, sh,
                    bt.data_ptr(), bt.stride(0), ctx.data_ptr(), out.data_ptr(), out.stride(0),
                    out.stride(1), pa, pm, tk, scale, B, hq, hkv, d, k_cache.shape[1], ns, _dt(q),
-                   _kv_fp8(k_cache), _stream()), "paged_attention_decode")
+                   _kv_fp8(k_cache), *fuse, _stream()), "paged_attention_decode")
     return out
 
 

@@ -304,6 +304,83 @@ def test_paged_decode(hip, dtype, hq, hkv, d, bs):
     close(got, want, dtype)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("hq,hkv,d", [(32, 8, 128), (16, 8, 128), (8, 1, 128), (16, 8, 64), (4, 4, 128),
+                                      (40, 8, 128), (64, 4, 128), (40, 2, 128)])
+@pytest.mark.parametrize("bs", [16, 256])
+@pytest.mark.parametrize("with_norm", [True, False])
+def test_paged_decode_with_fused_norm_rope_store(hip, dtype, hq, hkv, d, bs, with_norm):
+    """Decode attention handed the raw q / k / v projections: against the stand-alone
+    norm + rotate + store kernel followed by the plain decode kernel, with unused batch
+    rows (length 0), contexts of one token and contexts that end on, before and behind a 32-token
+    tile or a cache block; the slot of the new token holds NaN beforehand."""
+    torch.manual_seed(80 + hq)
+    lens = [1, 31, 32, 33, 0, 260, 1000, 77, 256, 257, 0, 64]
+    B = len(lens)
+    eps, scale = 1e-6, 1.0 / math.sqrt(d)
+    # the cache holds the first L - 1 tokens; the last token's slot is poisoned
+    old = [max(L - 1, 0) for L in lens]
+    k = torch.randn(sum(old), hkv, d, device=DEV, dtype=dtype)
+    v = torch.randn(sum(old), hkv, d, device=DEV, dtype=dtype)
+    nblk = [(max(L, 1) + bs - 1) // bs for L in lens]
+    perm = torch.randperm(sum(nblk) + 3)
+    kc, vc = _logical_cache(sum(nblk) + 3, bs, hkv, d, dtype), _logical_cache(sum(nblk) + 3, bs, hkv, d, dtype)
+    tables = torch.full((B, max(nblk)), -1, dtype=torch.int32)
+    used = 0
+    for i in range(B):
+        tables[i, :nblk[i]] = perm[used:used + nblk[i]].to(torch.int32)
+        used += nblk[i]
+    tables = tables.to(DEV)
+    off = 0
+    slots = []
+    for i, L in enumerate(lens):
+        for t in range(max(L - 1, 0)):
+            blk = int(tables[i, t // bs])
+            kc[blk, t % bs] = k[off + t]
+            vc[blk, t % bs] = v[off + t]
+        off += max(L - 1, 0)
+        if L > 0:
+            blk = int(tables[i, (L - 1) // bs])
+            kc[blk, (L - 1) % bs] = float("nan")
+            vc[blk, (L - 1) % bs] = float("nan")
+            slots.append(blk * bs + (L - 1) % bs)
+        else:
+            slots.append(-1)
+    qkv = torch.randn(B, (hq + 2 * hkv) * d, device=DEV, dtype=dtype)
+    qw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype) if with_norm else None
+    kw = (1 + 0.1 * torch.randn(d, device=DEV)).to(dtype) if with_norm else None
+    cs = ref.build_cos_sin_cache(d, 2048, 10000.0, DEV)
+    ctx = torch.tensor(lens, device=DEV, dtype=torch.int32)
+    pos = (ctx - 1).clamp(min=0)
+    slot_t = torch.tensor(slots, device=DEV, dtype=torch.int32)
+    # unfused: store kernel (in place on a copy), then the plain decode kernel
+    kc1, vc1, qkv1 = kc.clone(), vc.clone(), qkv.clone()
+    # (clone() of the permuted view keeps the logical shape; make it head-major again)
+    kc1 = kc1.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    vc1 = vc1.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+    q1, _, _ = hip.qk_norm_rope_store(qkv1, pos, cs, qw, kw, eps, hq, hkv, d, kc1, vc1, slot_t)
+    live = torch.tensor([L > 0 for L in lens], device=DEV)
+    for ns in (1, 4):
+        kc2 = kc.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+        vc2 = vc.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)
+        want = hip.paged_attention_decode(q1, kc1, vc1, tables, ctx, scale, num_splits=ns)
+        q = qkv[:, :hq * d].view(B, hq, d)
+        kn = qkv[:, hq * d:(hq + hkv) * d].view(B, hkv, d)
+        vn = qkv[:, (hq + hkv) * d:].view(B, hkv, d)
+        got = hip.paged_attention_decode(q, kc2, vc2, tables, ctx, scale, num_splits=ns,
+                                         new_kv=(kn, vn, cs, qw, kw, eps))
+        # every slot, touched or not; keys to one rounding step (the two kernels sum the squares
+        # of a row in different orders)
+        assert torch.equal(vc2, vc1) and not torch.isnan(kc2).any()
+        ulp = 2.0 ** (-7 if dtype == torch.bfloat16 else -10)
+        assert float(((kc2.float() - kc1.float()).abs() / kc1.float().abs().clamp(min=0.25)).max()) <= ulp
+        assert not torch.isnan(got[live]).any()
+        close(got[live], want[live].float(), dtype)
+    # and against the fp32 oracle on the transformed inputs
+    oracle = ref.paged_attention_decode(q1[live], kc1, vc1, tables[live], ctx[live], scale)
+    close(got[live], oracle, dtype)
+
+
 def test_paged_decode_split_merge_tickets(hip):
     """The context splits are merged by the workgroup that finishes last (a ticket per
     (sequence, head group)).  Many back-to-back launches with different split counts and batch
