@@ -340,6 +340,25 @@ def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int, conser
     return {"error": f"{phase} phase printed no result"}
 
 
+_RESULT_OUT = None
+
+
+def claim_stdout() -> None:
+    """The one JSON line goes to the process's original stdout; from here on file descriptor 1
+    is stderr, so that nothing a library prints there (RCCL's version banner when its first
+    communicator comes up) can end up next to the result."""
+    global _RESULT_OUT
+    sys.stdout.flush()
+    _RESULT_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
+
+def emit(obj) -> None:
+    out = _RESULT_OUT or sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def published_reference_check():
     """The only numbers the reference publishes: SiluAndMul fp32 timings on one A6000."""
     try:
@@ -490,13 +509,14 @@ def main():
                      "(one rank per GPU)")
         args.gpus = world
 
+    claim_stdout()
     phase = os.environ.get("MINIVLLM_BENCH_PHASE")
     if phase:                                    # child of an orchestrating rank
         res = run_phase(args, phase, rank, local_rank, world)
         if rank == 0:
             if phase in ("dp", "tp"):
                 res["published_reference_check"] = published_reference_check()
-            print(json.dumps(res), flush=True)
+            emit(res)
         return
 
     B = args.batch
@@ -527,7 +547,7 @@ def main():
                "published_reference_check": published_reference_check()}
         if second is not None:
             out["secondary"] = {"model": args.second_model, **_round(second)}
-        print(json.dumps(out), flush=True)
+        emit(out)
         return
 
     # ---- N > 1: orchestrate one child per phase --------------------------------------
@@ -568,7 +588,7 @@ def main():
         out["tensor_parallel_first_attempt"] = tp_first
         out["tensor_parallel_retry"] = "conservative engine settings (MINIVLLM_TP_CONSERVATIVE=1)"
     out["gpu_state"] = gpu_state()
-    print(json.dumps(out), flush=True)
+    emit(out)
     if not good:
         sys.exit(1)
 

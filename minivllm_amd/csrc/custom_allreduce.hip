@@ -4,11 +4,18 @@
 // The 8 GPUs of a node are fully connected by point-to-point xGMI links, so a rank can pull from
 // all 7 peers at once, one link each.  For the messages of a decode step ([B, hidden] bf16, tens
 // of KB to a few MB) a ring collective is latency-bound (2 (P - 1) dependent hops); here the
-// whole operation is ONE kernel per rank with three flag barriers:
+// whole operation is ONE kernel per rank with one or two flag barriers:
 //
 //   one-shot (small):  copy x -> my staging buffer | barrier | x = sum over ranks of staging
 //   two-shot:          copy | barrier | reduce MY 1/P slice from all ranks' staging into my
-//                      result buffer | barrier | gather the P reduced slices | barrier
+//                      result buffer | barrier | gather the P reduced slices
+//   No barrier closes a call.  What a later call overwrites is protected by the barriers it has
+//   to pass first, given that a rank's calls run one after the other (stream order): a staging
+//   buffer exists twice and calls alternate between the halves, so when call n + 2 writes the
+//   half of call n every peer has signalled the first barrier of call n + 1, which it reaches
+//   only after its kernel of call n - all of its reads - has finished; a result buffer is
+//   written behind the first barrier of its call, by which time every peer has entered that
+//   call and is done with the previous one.
 //   one-shot + norm:   the one-shot form for [rows, hidden] inputs with the consumer folded in:
 //                      a block owns whole rows, so after the sum it adds the residual stream,
 //                      stores the new residual and writes the RMS-normalised row - the
@@ -51,7 +58,8 @@ constexpr int kThreads = 512;
 constexpr long kDefaultTimeoutTicks = 200000000L;      // 2 s of the 100 MHz counter
 
 // One per rank, in peer-visible memory.  counter[phase][block][src rank] is written by rank
-// `src`; epoch[block] is this rank's own call count (one more per launch).
+// `src`; epoch[block] is this rank's own call count (one more per launch, for every block whether
+// the launch had that many blocks or not: the count's parity selects the staging half).
 struct Flags {
     uint32_t counter[3][kMaxBlocks][kMaxRanks];
     uint32_t epoch[kMaxBlocks];
@@ -62,6 +70,7 @@ struct Peers {
     Flags* flags[kMaxRanks];
     uint16_t* stage[kMaxRanks];                // inputs, one buffer per rank
     uint16_t* result[kMaxRanks];               // reduced slices (two-shot)
+    long stage_half;                           // elements of one half of a staging buffer
     long timeout_ticks;                        // longest wait for a peer, in 10 ns ticks
     // Rehearsal of one rank of a P-way group on a single GPU: every table entry is this rank's
     // own allocation and lane p of a barrier plays peer p (it raises the flag that peer would
@@ -111,6 +120,14 @@ __device__ __forceinline__ bool block_barrier(const Peers& pr, int rank, int pha
     return __syncthreads_or(failed) == 0;
 }
 
+// Last statement of a call: the block's call count advances; block 0 also advances the counts of
+// the block indices this launch did not have.
+__device__ __forceinline__ void finish_call(Flags* mine, uint32_t epoch) {
+    if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+    if (blockIdx.x == 0 && threadIdx.x >= gridDim.x && threadIdx.x < kMaxBlocks)
+        mine->epoch[threadIdx.x] = epoch;
+}
+
 template <int CODE>
 __device__ __forceinline__ void accumulate(float (&acc)[8], u32x4_t v) {
     float f[8];
@@ -128,31 +145,31 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank
     const long stride = (long)gridDim.x * kThreads;
     const long first = (long)blockIdx.x * kThreads + threadIdx.x;
     u32x4_t* xv = reinterpret_cast<u32x4_t*>(x);
+    const long hv = (long)(epoch & 1) * (pr.stage_half / 8);        // this call's staging half, in vectors
 
     // a peer that never arrived: this block's share of the output becomes NaN (never a sum over
     // buffers that may not have been written), the call count still advances
     auto give_up = [&]() {
         for (long i = first; i < n_vec; i += stride) xv[i] = nan_vec<CODE>();
-        if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+        finish_call(mine, epoch);
     };
     if (!TWO_SHOT) {
-        u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
+        u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]) + hv;
         for (long i = first; i < n_vec; i += stride) st[i] = xv[i];
         if (!block_barrier<P>(pr, rank, 0, epoch, true)) { give_up(); return; }
         for (long i = first; i < n_vec; i += stride) {
             u32x4_t v[P];
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                v[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[i];
+                v[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[hv + i];
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int p = 0; p < P; ++p) accumulate<CODE>(acc, v[p]);  // rank order: same bits everywhere
             xv[i] = pack8<CODE>(acc);
         }
-        block_barrier<P>(pr, rank, 2, epoch, false);        // peers are done reading my staging
     } else {
         const long part = n_vec / P;                         // vectors per slice
-        u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
+        u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]) + hv;
         // block b moves the same relative subset of EVERY slice, on every rank
         for (int s = 0; s < P; ++s)
             for (long i = first; i < part; i += stride) st[s * part + i] = xv[s * part + i];
@@ -162,7 +179,7 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank
             u32x4_t v[P];
 #pragma unroll
             for (int p = 0; p < P; ++p)
-                v[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[rank * part + i];
+                v[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[hv + rank * part + i];
             float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int p = 0; p < P; ++p) accumulate<CODE>(acc, v[p]);
@@ -180,9 +197,8 @@ __global__ __launch_bounds__(kThreads) void all_reduce_kernel(Peers pr, int rank
             for (int p = 0; p < P; ++p)
                 if (p != rank) xv[p * part + i] = v[p];
         }
-        block_barrier<P>(pr, rank, 2, epoch, false);        // peers are done reading my buffers
     }
-    if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+    finish_call(mine, epoch);
 }
 
 // What a rank contributes to a fused reduce + norm: its [rows, hidden] partial sums in the
@@ -214,11 +230,11 @@ __device__ __forceinline__ u32x4_t load_chunk(const RowSource& s, long at) {
 // the all-reduce rounds; + residual chunk, rounded as the add + norm kernel rounds.  Returns the
 // chunk's share of the sum of squares.
 template <int CODE, int P>
-__device__ __forceinline__ float reduce_add_chunk(const Peers& pr, long at, u32x4_t* res_chunk,
+__device__ __forceinline__ float reduce_add_chunk(const Peers& pr, long hv, long at, u32x4_t* res_chunk,
                                                   float (&v)[8]) {
     u32x4_t pv[P];
 #pragma unroll
-    for (int p = 0; p < P; ++p) pv[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[at];
+    for (int p = 0; p < P; ++p) pv[p] = reinterpret_cast<const u32x4_t*>(pr.stage[p])[hv + at];
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int p = 0; p < P; ++p) accumulate<CODE>(acc, pv[p]);
@@ -250,7 +266,8 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
     const int nchunk = hidden >> 3;
     u32x4_t* ov = reinterpret_cast<u32x4_t*>(out);
     u32x4_t* rv = reinterpret_cast<u32x4_t*>(residual);
-    u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
+    const long hv = (long)(epoch & 1) * (pr.stage_half / 8);
+    u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]) + hv;
 
     for (int row = blockIdx.x; row < rows; row += gridDim.x)
 #pragma unroll
@@ -265,7 +282,7 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
                 const int c = threadIdx.x + i * blockDim.x;
                 if (c < nchunk) ov[(long)row * nchunk + c] = nan_vec<CODE>();
             }
-        if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+        finish_call(mine, epoch);
         return;
     }
 
@@ -278,7 +295,7 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
             const int c = threadIdx.x + i * blockDim.x;
             if (c < nchunk) {
                 const long at = (long)row * nchunk + c;
-                ss += reduce_add_chunk<CODE, P>(pr, at, rv + at, v[i]);
+                ss += reduce_add_chunk<CODE, P>(pr, hv, at, rv + at, v[i]);
             }
         }
         ss = block_sum(ss, scratch);
@@ -295,8 +312,7 @@ __global__ __launch_bounds__(1024) void all_reduce_norm_kernel(
             }
         }
     }
-    block_barrier<P>(pr, rank, 2, epoch, false);            // peers are done reading my staging
-    if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+    finish_call(mine, epoch);
 }
 
 // Two-shot form with a row-sharded residual stream: `residual` is THIS rank's [rows / P, hidden]
@@ -314,7 +330,8 @@ __global__ __launch_bounds__(1024) void all_reduce_norm2_kernel(
     const int R = rows / P;
     u32x4_t* ov = reinterpret_cast<u32x4_t*>(out);
     u32x4_t* rv = reinterpret_cast<u32x4_t*>(residual);
-    u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]);
+    const long hv = (long)(epoch & 1) * (pr.stage_half / 8);
+    u32x4_t* st = reinterpret_cast<u32x4_t*>(pr.stage[rank]) + hv;
     u32x4_t* res = reinterpret_cast<u32x4_t*>(pr.result[rank]);
 
     auto poison = [&]() {
@@ -325,17 +342,30 @@ __global__ __launch_bounds__(1024) void all_reduce_norm2_kernel(
                     const int c = threadIdx.x + i * blockDim.x;
                     if (c < nchunk) ov[(long)(s * R + j) * nchunk + c] = nan_vec<CODE>();
                 }
-        if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+        finish_call(mine, epoch);
     };
 
-    for (int s = 0; s < P; ++s)
-        for (int j = blockIdx.x; j < R; j += gridDim.x) {
-            const long base = (long)(s * R + j) * nchunk;
+    // the block's row of several slices at a time: all of their loads are in flight before the
+    // first store (a decode batch leaves a block ONE row per slice: slice after slice, every
+    // store waiting for its own load, was 8 dependent round trips)
+    constexpr int SB = MAXC <= 2 ? P : 2;
+    for (int j = blockIdx.x; j < R; j += gridDim.x)
+        for (int s0 = 0; s0 < P; s0 += SB) {
+            u32x4_t tmp[SB][MAXC];
 #pragma unroll
-            for (int i = 0; i < MAXC; ++i) {
-                const int c = threadIdx.x + i * blockDim.x;
-                if (c < nchunk) st[base + c] = load_chunk<CODE>(src, base + c);
-            }
+            for (int s = 0; s < SB; ++s)
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = threadIdx.x + i * blockDim.x;
+                    if (c < nchunk) tmp[s][i] = load_chunk<CODE>(src, (long)((s0 + s) * R + j) * nchunk + c);
+                }
+#pragma unroll
+            for (int s = 0; s < SB; ++s)
+#pragma unroll
+                for (int i = 0; i < MAXC; ++i) {
+                    const int c = threadIdx.x + i * blockDim.x;
+                    if (c < nchunk) st[(long)((s0 + s) * R + j) * nchunk + c] = tmp[s][i];
+                }
         }
     if (!block_barrier<P>(pr, rank, 0, epoch, true)) { poison(); return; }
 
@@ -347,7 +377,7 @@ __global__ __launch_bounds__(1024) void all_reduce_norm2_kernel(
 #pragma unroll
         for (int i = 0; i < MAXC; ++i) {
             const int c = threadIdx.x + i * blockDim.x;
-            if (c < nchunk) ss += reduce_add_chunk<CODE, P>(pr, base + c, rv + (long)j * nchunk + c, v[i]);
+            if (c < nchunk) ss += reduce_add_chunk<CODE, P>(pr, hv, base + c, rv + (long)j * nchunk + c, v[i]);
         }
         ss = block_sum(ss, scratch);
         const float rstd = rsqrtf(ss / (float)hidden + eps);
@@ -381,8 +411,7 @@ __global__ __launch_bounds__(1024) void all_reduce_norm2_kernel(
                     if (p != rank) ov[(long)(p * R + j) * nchunk + c] = v[p];
             }
         }
-    block_barrier<P>(pr, rank, 2, epoch, false);            // peers are done reading my buffers
-    if (threadIdx.x == 0) mine->epoch[blockIdx.x] = epoch;
+    finish_call(mine, epoch);
 }
 
 template <int CODE, int P>
@@ -476,7 +505,9 @@ static long g_loopback = 0;
 // the pointer tables as all-own and lets barrier lane p stand in for peer p.
 extern "C" void mvl_car_set_loopback(int on) { g_loopback = on; }
 
-static void fill_peers(Peers& pr, void* const* flags, void* const* stage, void* const* result, int world) {
+static void fill_peers(Peers& pr, void* const* flags, void* const* stage, void* const* result, int world,
+                       long stage_half_bytes) {
+    pr.stage_half = stage_half_bytes / 2;
     for (int p = 0; p < world; ++p) {
         pr.flags[p] = (Flags*)flags[p];
         pr.stage[p] = (uint16_t*)stage[p];
@@ -487,16 +518,19 @@ static void fill_peers(Peers& pr, void* const* flags, void* const* stage, void* 
 }
 
 // flags / stage / result: `world` device pointers each, indexed by rank (own entries are the
-// local allocations, the others IPC mappings).  x: [n_elems] 16-bit elements, in place.
+// local allocations, the others IPC mappings).  A staging buffer is two halves of
+// stage_half_bytes (a multiple of 16) each, a result buffer one.  x: [n_elems] 16-bit elements,
+// in place.
 extern "C" int mvl_car_all_reduce(void* const* flags, void* const* stage, void* const* result,
                                   int world, int rank, void* x, long n_elems, int two_shot,
-                                  int dtype, void* stream) {
+                                  int dtype, long stage_half_bytes, void* stream) {
     if (n_elems == 0) return 0;
     if (world > kMaxRanks || n_elems % 8 != 0 || ((uintptr_t)x & 15) != 0) return -1;
+    if (stage_half_bytes % 16 != 0 || n_elems * 2 > stage_half_bytes) return -1;
     const long n_vec = n_elems / 8;
     if (two_shot && n_vec % world != 0) return -1;
     Peers pr;
-    fill_peers(pr, flags, stage, result, world);
+    fill_peers(pr, flags, stage, result, world, stage_half_bytes);
     auto st = (hipStream_t)stream;
     return dtype == 0 ? launch_p<0>(pr, world, rank, x, n_vec, two_shot != 0, st)
                       : launch_p<1>(pr, world, rank, x, n_vec, two_shot != 0, st);
@@ -507,20 +541,21 @@ extern "C" int mvl_car_all_reduce(void* const* flags, void* const* stage, void* 
 // given, the fp32 K-slice partials [nparts][rows][hidden] that sum to it.
 // two_shot == 0: `residual` is the full [rows, hidden] stream (replicated on every rank).
 // two_shot != 0: rows % world == 0 and `residual` is this rank's [rows / world, hidden] slice.
-// rows * hidden * 2 bytes must fit the staging (and result) buffer: the caller checks.
+// rows * hidden * 2 bytes must fit half the staging buffer and the result buffer.
 extern "C" int mvl_car_all_reduce_norm(void* const* flags, void* const* stage, void* const* result,
                                        int world, int rank, const void* x, const float* parts,
                                        int nparts, void* out, void* residual, const void* gamma,
                                        int rows, int hidden, float eps, int two_shot, int dtype,
-                                       void* stream) {
+                                       long stage_half_bytes, void* stream) {
     if (rows == 0) return 0;
+    if (stage_half_bytes % 16 != 0 || (long)rows * hidden * 2 > stage_half_bytes) return -1;
     if (world > kMaxRanks || hidden % 8 != 0 || hidden > 8 * 1024 * 4 ||
         (((uintptr_t)x | (uintptr_t)parts | (uintptr_t)out | (uintptr_t)residual | (uintptr_t)gamma) & 15) != 0)
         return -1;
     if (two_shot && (rows % world != 0 || result == nullptr)) return -1;
     if (parts == nullptr ? x == nullptr : nparts < 1) return -1;
     Peers pr;
-    fill_peers(pr, flags, stage, result, world);
+    fill_peers(pr, flags, stage, result, world, stage_half_bytes);
     RowSource src;
     src.x = (const uint16_t*)x; src.parts = parts; src.nparts = nparts; src.slab = (long)rows * hidden;
     auto st = (hipStream_t)stream;

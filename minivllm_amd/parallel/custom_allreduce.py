@@ -74,10 +74,10 @@ class CustomAllReduce:
         lib.mvl_car_ipc_close.argtypes = [vp]
         lib.mvl_car_status.argtypes = [vp]
         lib.mvl_car_all_reduce.argtypes = [ctypes.POINTER(vp)] * 3 + [
-            ctypes.c_int, ctypes.c_int, vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, vp]
+            ctypes.c_int, ctypes.c_int, vp, ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_long, vp]
         lib.mvl_car_all_reduce_norm.argtypes = [ctypes.POINTER(vp)] * 3 + [
             ctypes.c_int, ctypes.c_int, vp, vp, ctypes.c_int, vp, vp, vp, ctypes.c_int,
-            ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, vp]
+            ctypes.c_int, ctypes.c_float, ctypes.c_int, ctypes.c_int, ctypes.c_long, vp]
         lib.mvl_car_set_loopback.argtypes = [ctypes.c_int]
         lib.mvl_car_set_loopback.restype = None
         lib.mvl_car_set_loopback(int(loopback))
@@ -87,7 +87,10 @@ class CustomAllReduce:
         self._hbytes = lib.mvl_car_ipc_handle_bytes()
         torch.cuda.set_device(device)
         # flags, staging, result: fine-grained (uncached) allocations, coherent across the GPUs
-        sizes = [lib.mvl_car_flags_bytes(), max_bytes, max_bytes]
+        # (the staging buffer is two halves that consecutive calls alternate between: no call has
+        # to wait for its peers to finish reading before it returns)
+        assert max_bytes % 16 == 0
+        sizes = [lib.mvl_car_flags_bytes(), 2 * max_bytes, max_bytes]
         self._own: List[int] = []
         self._mapped: List[int] = []
         handles, err = [], None
@@ -160,7 +163,7 @@ class CustomAllReduce:
         two_shot = x.numel() * 2 > self.one_shot_max_bytes
         rc = self._lib.mvl_car_all_reduce(
             self._flags, self._stage, self._result, self.world, self.rank, x.data_ptr(),
-            x.numel(), int(two_shot), 0 if x.dtype == torch.bfloat16 else 1,
+            x.numel(), int(two_shot), 0 if x.dtype == torch.bfloat16 else 1, self.max_bytes,
             torch.cuda.current_stream().cuda_stream)
         self._ck(rc, "launch")
         self.calls += 1
@@ -227,7 +230,8 @@ class CustomAllReduce:
         rc = self._lib.mvl_car_all_reduce_norm(
             self._flags, self._stage, self._result, self.world, self.rank, xp, parts, nparts,
             out.data_ptr(), res_ptr, gamma.data_ptr(), rows, hidden, float(eps), int(two_shot),
-            0 if dtype == torch.bfloat16 else 1, torch.cuda.current_stream().cuda_stream)
+            0 if dtype == torch.bfloat16 else 1, self.max_bytes,
+            torch.cuda.current_stream().cuda_stream)
         self._ck(rc, "launch")
         self.calls += 1
         self.fused_norm_calls += 1

@@ -7,4 +7,6 @@ run() {  # name extra-args
   python3 $R/tools/prof_summary.py $f --marker sample_kernel --last-steps 6 > $O/$n.txt 2>&1
   head -12 $O/$n.txt; rm -rf $O/$n
 }
-run dec8b --model qwen3-8b && run dec8b_tp8 --model qwen3-8b --tp-shard 8 && run dec8b_b1 --model qwen3-8b --batch 1
+[ "$1" = p2p ] || { run dec8b --model qwen3-8b && run dec8b_tp8 --model qwen3-8b --tp-shard 8 && run dec8b_b1 --model qwen3-8b --batch 1; }
+# the same rank with the peer-to-peer all-reduce kernels in loop-back form
+[ "$1" = p2p ] && run dec8b_tp8_p2p --model qwen3-8b --tp-shard 8 --p2p
