@@ -24,6 +24,10 @@ GEOMETRIES = {
                    num_layers=3),
     "32q8kv": dict(hidden_size=1024, num_heads=32, num_kv_heads=8, intermediate_size=2048,
                    num_layers=2),
+    # five query heads per KV head, biased QKV projection and no q/k norm (Qwen2.5-style): the
+    # attention kernels' transforms run without norm weights
+    "40q8kv-bias": dict(hidden_size=1024, num_heads=40, num_kv_heads=8, intermediate_size=2048,
+                        num_layers=2, qkv_bias=True),
 }
 REL_TOL = 0.03            # vs the fp32 oracle (observed: about 0.01)
 REL_TOL_SAME = 0.015      # GPU against GPU through another path (graph / chunked / cached)
