@@ -151,14 +151,17 @@ class EngineConfig:
     # takes its work from a list in device memory, so a graph's launch shapes depend on the
     # step's budgets only.  Graphs for steps of at most prefill_graph_max_tokens new tokens and
     # prefill_graph_max_seqs sequences are captured at start-up; with prefill_graph_lazy every
-    # other pure prefill step shape is captured the first time it occurs (that step runs
-    # eagerly on the graph's static buffers and is then recorded), up to
-    # prefill_graph_max_graphs graphs.  prefill_graph_max_tokens = 0: always launch eagerly.
-    # Mixed prefill + decode steps are not captured.
+    # other prefill step shape - mixed prefill + decode steps included, whose decode rows take
+    # the first slots of the batch - is captured when it occurs for the
+    # prefill_graph_capture_after-th time (that step runs eagerly on the graph's static buffers
+    # and is then recorded; a capture costs about two steps of its shape, so shapes that never
+    # come back are not worth one), up to prefill_graph_max_graphs graphs.
+    # prefill_graph_max_tokens = 0: always launch eagerly.
     prefill_graph_max_tokens: int = 1024
     prefill_graph_max_seqs: int = 8
     prefill_graph_lazy: bool = True
     prefill_graph_max_graphs: int = 96
+    prefill_graph_capture_after: int = 2
 
     def prefill_graph_limits(self) -> tuple:
         """(max tokens, max sequences) of the prefill graphs captured at start-up."""

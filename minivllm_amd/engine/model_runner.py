@@ -53,8 +53,8 @@ class Batch:
     has_prefix: bool = False
     step: int = 0
     tables_unchanged: bool = False      # decode: block tables equal the previous step's
-    # mixed step: the last num_decode_seqs sequences of a prefill-form batch contribute one
-    # decode row each, placed behind the num_prefill_tokens prompt rows
+    # mixed step: the FIRST num_decode_seqs sequences of a prefill-form batch contribute one
+    # decode row each (rows 0 .. num_decode_seqs - 1), the num_prefill_tokens prompt rows follow
     num_decode_seqs: int = 0
     num_prefill_tokens: int = 0
     num_prefill_k_tokens: int = 0       # sum of the context lengths of the prefill sequences
@@ -62,6 +62,8 @@ class Batch:
     # this one's read-back, and every worker has to enqueue that step too
     prelaunch: bool = False
     arrays: Dict[str, np.ndarray] = field(default_factory=dict)
+    # set where the step executes: decode slots of the captured graph that ran a mixed step
+    decode_slots: Optional[int] = None
 
     def scalars(self) -> dict:
         return dict(is_prefill=self.is_prefill, num_seqs=self.num_seqs, num_tokens=self.num_tokens,
@@ -412,6 +414,9 @@ class ModelRunner:
         # attention grid and LM-head rows are sized for the bucket)
         S = cfg.max_num_sequences
         self._pg_seq_buckets = sorted({min(self.pg_max_seqs, S), min(32, S), min(128, S), S})
+        # decode-slot buckets of mixed steps (the riders' rows at the front of the batch)
+        self._pg_dec_buckets = sorted({min(1 << i, S) for i in range(0, 12)})
+        self._pg_seen: Dict[tuple, int] = {}
         self._pg_off = {}
         if self._pg_sizes:
             from minivllm_amd.ops import hip
@@ -420,7 +425,7 @@ class ModelRunner:
             self._pg_tmax, self._pg_smax, off = tmax, smax, 0
             for name, n in (("input_ids", tmax), ("positions", tmax), ("slot_mapping", tmax),
                             ("cu_seqlens_q", smax + 1), ("cu_seqlens_k", smax + 1),
-                            ("temperatures", smax), ("misc", 4),
+                            ("temperatures", smax), ("misc", 4), ("context_lens", smax),
                             ("prefill_items", hip.prefill_item_slots(tmax, smax)),
                             ("block_tables", smax * MB)):
                 self._pg_off[name] = (off, n)
@@ -610,23 +615,28 @@ class ModelRunner:
     def prepare_prefill(self, seqs: Seq[Sequence], num_decode: int = 0) -> Batch:
         """``num_decode``: the last that many sequences are running sequences that ride along
         with one decode token each (mixed step); their row is the newest token, whose key is
-        everything before it in the paged cache."""
+        everything before it in the paged cache.  Inside the batch the riders come FIRST (rows
+        and sequence slots 0 .. num_decode - 1), the prompts behind them: the decode rows of a
+        step then sit at a fixed place whatever the prompts' lengths are, which is what lets a
+        captured graph serve mixed steps.  ``execute`` hands the tokens back in the caller's
+        order."""
         bs = self.block_size
+        if num_decode:
+            seqs = list(seqs[len(seqs) - num_decode:]) + list(seqs[:len(seqs) - num_decode])
         B = len(seqs)
-        first_decode = B - num_decode
         starts = np.empty(B, np.int64)
         ends = np.empty(B, np.int64)
         ids = []
         for i, seq in enumerate(seqs):
-            if i >= first_decode:
+            if i < num_decode:
                 starts[i], ends[i] = seq.num_tokens - 1, seq.num_tokens
             else:
                 starts[i] = seq.num_cached_tokens
                 ends[i] = seq.num_tokens if seq.prefill_end is None else seq.prefill_end
             ids.append(seq.token_array(int(starts[i]), int(ends[i])))
         lens = ends - starts
-        max_q = int(lens[:first_decode].max()) if first_decode else 0
-        max_ctx = int(ends[first_decode:].max()) if num_decode else 0
+        max_q = int(lens[num_decode:].max()) if B > num_decode else 0
+        max_ctx = int(ends[:num_decode].max()) if num_decode else 0
         max_k = int(ends.max())
         has_prefix = num_decode > 0 or bool(starts.any())
         cu_q = np.zeros(B + 1, np.int64)
@@ -661,15 +671,16 @@ class ModelRunner:
                       temperatures=np.asarray([s.temperature for s in seqs], np.float32),
                       block_tables=tables)
         if num_decode:
-            arrays["context_lens"] = np.asarray([s.num_tokens for s in seqs[first_decode:]], np.int32)
+            arrays["context_lens"] = ends[:num_decode].astype(np.int32)
         if self.on_gpu:
             # the attention kernel's work list: one entry per pair of query tiles of a prompt
+            # (sequence numbers count from the first prompt)
             from minivllm_amd.ops import hip
-            arrays["prefill_items"] = hip.prefill_work_items(lens[:first_decode], ends[:first_decode])
+            arrays["prefill_items"] = hip.prefill_work_items(lens[num_decode:], ends[num_decode:])
         self._add_filter_arrays(arrays, seqs)
         return Batch(is_prefill=True, num_seqs=B, num_tokens=int(input_ids.size),
                      max_seqlen_q=max_q, max_seqlen_k=max_k, has_prefix=has_prefix,
-                     num_prefill_k_tokens=int(cu_k[first_decode]),
+                     num_prefill_k_tokens=int(cu_k[-1] - cu_k[num_decode]),
                      max_context_len=max_ctx, num_decode_seqs=num_decode,
                      num_prefill_tokens=num_prefill_tokens, arrays=arrays)
 
@@ -1029,6 +1040,10 @@ class ModelRunner:
                 pg.check_custom_all_reduce(synchronize=True)     # workers: now and then
             return None
         out = tokens.tolist()
+        if b.is_prefill and b.num_decode_seqs:           # riders first inside, last for the caller
+            Bd = b.num_decode_seqs
+            db = b.decode_slots if b.decode_slots is not None else Bd    # a graph's decode slots
+            out = out[db:db + b.num_seqs - Bd] + out[:Bd]
         # the read-back has drained the stream: looking at the peer-to-peer all-reduce's status
         # word costs one small copy, so every step of rank 0 can afford it
         pg.check_custom_all_reduce(synchronize=False)
@@ -1204,7 +1219,7 @@ class ModelRunner:
         self._capture_prefill_graphs()
 
     # ------------------------------------------------------------ prefill graphs
-    def _pg_tensors(self, tb: int, sb: int) -> dict:
+    def _pg_tensors(self, tb: int, sb: int, db: int = 0) -> dict:
         d = self._pg_dev
         MB = self.max_blocks_per_seq
         from minivllm_amd.ops import hip
@@ -1216,34 +1231,53 @@ class ModelRunner:
                     slot_mapping=v("slot_mapping", tb), cu_seqlens_q=v("cu_seqlens_q", sb + 1),
                     cu_seqlens_k=v("cu_seqlens_k", sb + 1),
                     temperatures=v("temperatures", sb).view(torch.float32), step=v("misc"),
+                    context_lens=v("context_lens", db),
                     prefill_items=v("prefill_items", hip.prefill_item_slots(tb, sb)),
                     positions_in_context=True,
                     block_tables=v("block_tables", sb * MB).view(sb, MB))
 
     def _prefill_graph_key(self, b: Batch):
-        """(token bucket, sequence bucket) of the graph that serves this prefill step, or None
-        when the step launches eagerly: mixed steps, steps beyond the static buffers, shapes
-        whose capture failed, and - without lazy capture - anything not captured at start-up."""
-        if not self._pg_off or b.num_decode_seqs or self.enforce_eager:
+        """(token bucket, sequence-slot bucket, decode-slot bucket) of the graph that serves
+        this prefill step, or None when the step launches eagerly: steps beyond the static
+        buffers, shapes whose capture failed, mixed steps with restricted sampling, and - without
+        lazy capture - anything not captured at start-up.  A mixed step's riders take the first
+        ``db`` rows and sequence slots (unused ones have length 0), its prompts follow."""
+        if not self._pg_off or self.enforce_eager:
             return None
-        if b.num_tokens > self._pg_tmax or b.num_seqs > self._pg_smax \
+        Bd = b.num_decode_seqs
+        tb, slots, db = b.num_tokens, b.num_seqs, 0
+        if Bd:
+            if "top_k" in b.arrays:
+                return None
+            db = next((x for x in self._pg_dec_buckets if x >= Bd), None)
+            if db is None:
+                return None
+            tb = prefill_token_bucket(db + b.num_prefill_tokens)
+            slots = db + b.num_seqs - Bd
+        if tb > self._pg_tmax or slots > self._pg_smax \
                 or b.arrays["block_tables"].shape[1] > self.max_blocks_per_seq:
             return None
-        sb = next(x for x in self._pg_seq_buckets if x >= b.num_seqs)
-        key = (b.num_tokens, sb)
+        sb = next(x for x in self._pg_seq_buckets if x >= slots)
+        key = (tb, sb, db)
         if key in self.prefill_graphs:
             return key
         if (not self._pg_lazy or key in self._pg_failed
                 or len(self.prefill_graphs) >= self.cfg.prefill_graph_max_graphs
                 or "prefill_items" not in b.arrays):
             return None
-        return key
+        # a capture costs about two steps of this shape: only shapes that come back get one
+        # (every rank counts alike, so all of them capture at the same step)
+        seen = self._pg_seen.get(key, 0) + 1
+        self._pg_seen[key] = seen
+        return key if seen >= self.cfg.prefill_graph_capture_after else None
 
-    def _pg_step(self, t: dict, tb: int, sb: int):
+    def _pg_step(self, t: dict, tb: int, sb: int, db: int = 0):
         set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
                     max_seqlen_q=tb, max_seqlen_k=self.cfg.max_model_length,
                     slot_mapping=t["slot_mapping"], block_tables=t["block_tables"],
                     positions=t["positions"], num_seqs=sb, has_prefix=True,
+                    num_decode_seqs=db, context_lens=t["context_lens"] if db else None,
+                    max_context_len=self.cfg.max_model_length if db else 0,
                     prefill_items=t["prefill_items"], positions_in_context=True)
         out = self._forward_and_sample(t)
         reset_context()
@@ -1252,14 +1286,14 @@ class ModelRunner:
     def _capture_prefill_graph(self, key: tuple, warm_up: bool) -> None:
         """Record one prefill step on the static buffers.  ``warm_up``: run it once eagerly
         first (start-up captures; a lazy capture has just run the real step there)."""
-        tb, sb = key
-        t = self._pg_tensors(tb, sb)
+        tb, sb, db = key
+        t = self._pg_tensors(tb, sb, db)
         if warm_up:
-            self._pg_step(t, tb, sb)
+            self._pg_step(t, tb, sb, db)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, pool=self.graph_pool, capture_error_mode="thread_local"):
-            out = self._pg_step(t, tb, sb)
+            out = self._pg_step(t, tb, sb, db)
         if self.graph_pool is None:
             self.graph_pool = g.pool()
         self.prefill_graphs[key] = g
@@ -1287,25 +1321,45 @@ class ModelRunner:
         host[self._pg_off["prefill_items"][0]] = 0           # sequence 0, pair 0
         self._pg_dev.copy_(self._pg_host)
         for tb in reversed(self._pg_sizes):
-            self._capture_prefill_graph((tb, self._pg_seq_buckets[0]), warm_up=True)
+            self._capture_prefill_graph((tb, self._pg_seq_buckets[0], 0), warm_up=True)
         torch.cuda.synchronize()
 
     def _fill_prefill_graph_inputs(self, b: Batch, key: tuple) -> None:
         a = b.arrays
-        tb, sb = key
+        tb, sb, db = key
         B, MB = b.num_seqs, self.max_blocks_per_seq
+        Bd = b.num_decode_seqs
+        pad = db - Bd                      # unused decode slots: one row each, length 0
+        T = Bd + b.num_prefill_tokens      # real rows of the batch (riders, then prompts)
         from minivllm_amd.ops import hip
         host = self._pg_host.numpy()
-        for name in ("input_ids", "positions", "slot_mapping"):
+        for name, fill in (("input_ids", 0), ("positions", 0), ("slot_mapping", -1)):
             o, _ = self._pg_off[name]
-            host[o:o + tb] = a[name]
-        for name in ("cu_seqlens_q", "cu_seqlens_k"):       # unused slots: zero-length sequences
-            o, _ = self._pg_off[name]
-            host[o:o + B + 1] = a[name]
-            host[o + B + 1:o + sb + 1] = a[name][-1]
+            host[o:o + Bd] = a[name][:Bd]
+            host[o + Bd:o + db] = fill
+            host[o + db:o + pad + T] = a[name][Bd:T]
+            host[o + pad + T:o + tb] = fill
+        # sequence slots: riders, unused decode slots (a row each, no keys), prompts, unused
+        # slots (zero-length sequences)
+        o, _ = self._pg_off["cu_seqlens_q"]
+        host[o:o + db + 1] = np.arange(db + 1, dtype=np.int32)
+        host[o + db + 1:o + pad + B + 1] = a["cu_seqlens_q"][Bd + 1:] + pad
+        host[o + pad + B + 1:o + sb + 1] = a["cu_seqlens_q"][-1] + pad
+        o, _ = self._pg_off["cu_seqlens_k"]
+        host[o:o + Bd + 1] = a["cu_seqlens_k"][:Bd + 1]
+        host[o + Bd + 1:o + db + 1] = a["cu_seqlens_k"][Bd]
+        host[o + db + 1:o + pad + B + 1] = a["cu_seqlens_k"][Bd + 1:]
+        host[o + pad + B + 1:o + sb + 1] = a["cu_seqlens_k"][-1]
         o, _ = self._pg_off["temperatures"]
-        host[o:o + B] = a["temperatures"].astype(np.float32).view(np.int32)
-        host[o + B:o + sb] = 0
+        temps = a["temperatures"].astype(np.float32).view(np.int32)
+        host[o:o + Bd] = temps[:Bd]
+        host[o + Bd:o + db] = 0
+        host[o + db:o + pad + B] = temps[Bd:]
+        host[o + pad + B:o + sb] = 0
+        if db:
+            o, _ = self._pg_off["context_lens"]
+            host[o:o + Bd] = a["context_lens"]
+            host[o + Bd:o + db] = 0
         host[self._pg_off["misc"][0]] = b.step
         o, _ = self._pg_off["prefill_items"]
         slots = hip.prefill_item_slots(tb, sb)
@@ -1316,7 +1370,8 @@ class ModelRunner:
         tab = host[o:o + sb * MB].reshape(sb, MB)
         mb = a["block_tables"].shape[1]
         tab[:] = -1
-        tab[:B, :mb] = a["block_tables"]
+        tab[:Bd, :mb] = a["block_tables"][:Bd]
+        tab[db:pad + B, :mb] = a["block_tables"][Bd:]
         self._pg_dev.copy_(self._pg_host, non_blocking=True)
 
     def _run_prefill_graph(self, b: Batch, key: tuple):
@@ -1325,13 +1380,14 @@ class ModelRunner:
         recorded afterwards for the next time.  A capture that fails leaves the step done and
         the shape marked as eager-only."""
         self._fill_prefill_graph_inputs(b, key)
-        B = b.num_seqs
+        tb, sb, db = key
+        B = b.num_seqs + db - b.num_decode_seqs      # slots in use, unused decode slots included
+        b.decode_slots = db
         if key in self.prefill_graphs:
             self.prefill_graphs[key].replay()
             self.prefill_graph_replays += 1
             return self._pg_out[key][:B], self._pg_logits[key]
-        tb, sb = key
-        tokens = self._pg_step(self._pg_tensors(tb, sb), tb, sb)
+        tokens = self._pg_step(self._pg_tensors(tb, sb, db), tb, sb, db)
         tokens = tokens[:B].clone() if tokens is not None else None
         logits = self._last_logits
         try:

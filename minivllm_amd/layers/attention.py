@@ -136,24 +136,25 @@ class Attention(nn.Module):
         return o.reshape(T, self.num_heads * self.head_dim)
 
     def _mixed(self, q: torch.Tensor, ctx) -> torch.Tensor:
-        """Prompt rows through the prefill kernel, the decode rows behind them through the
-        decode kernel (a one-row query in the prefill kernel would stream the KV of its
-        sequence once per query head and fill 1 of 128 tile rows), one output buffer."""
+        """The decode rows (the first ``num_decode_seqs`` rows and sequence slots) through the
+        decode kernel, the prompt rows behind them through the prefill kernel (a one-row query
+        in the prefill kernel would stream the KV of its sequence once per query head and fill
+        1 of 128 tile rows), one output buffer.  Rows that belong to no sequence (padding of the
+        token bucket, unused slots of a captured step) are left as they are."""
         if self.k_cache is None or ctx.block_tables is None:
             raise RuntimeError("a mixed prefill + decode step needs an allocated KV cache")
         T = q.shape[0]
         Bd = ctx.num_decode_seqs
-        Bp, Tp = ctx.num_seqs - Bd, ctx.num_prefill_tokens
-        o = q.new_empty((T, self.num_heads, self.head_dim))
-        if Bp:
-            ops.paged_attention_prefill(q[:Tp], self.k_cache, self.v_cache,
-                                        ctx.cu_seqlens_q[:Bp + 1], ctx.cu_seqlens_k[:Bp + 1],
-                                        ctx.block_tables[:Bp], self.scale, ctx.max_seqlen_q,
-                                        out=o[:Tp], max_seqlen_k=ctx.max_seqlen_k,
+        o = q.new_empty((T, self.num_heads, self.head_dim)) if q.is_cuda \
+            else q.new_zeros((T, self.num_heads, self.head_dim))
+        if ctx.num_seqs > Bd:
+            # cu_seqlens hold absolute rows, so q and o go in whole
+            ops.paged_attention_prefill(q, self.k_cache, self.v_cache,
+                                        ctx.cu_seqlens_q[Bd:], ctx.cu_seqlens_k[Bd:],
+                                        ctx.block_tables[Bd:], self.scale, ctx.max_seqlen_q,
+                                        out=o, max_seqlen_k=ctx.max_seqlen_k,
                                         total_k=ctx.total_k_tokens, work_items=ctx.prefill_items)
-        ops.paged_attention_decode(q[Tp:Tp + Bd], self.k_cache, self.v_cache,
-                                   ctx.block_tables[Bp:], ctx.context_lens, self.scale,
-                                   ctx.max_context_len, out=o[Tp:Tp + Bd])
-        if T > Tp + Bd:
-            o[Tp + Bd:].zero_()                       # padding rows of the token bucket
+        ops.paged_attention_decode(q[:Bd], self.k_cache, self.v_cache,
+                                   ctx.block_tables[:Bd], ctx.context_lens, self.scale,
+                                   ctx.max_context_len, out=o[:Bd])
         return o.reshape(T, self.num_heads * self.head_dim)

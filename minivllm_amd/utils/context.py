@@ -28,9 +28,9 @@ class Context:
     max_context_len: int = 0                      # decode: upper bound of context_lens
     num_seqs: int = 0
     has_prefix: bool = False                      # prefill reads a cached prefix
-    # mixed step (a prefill-form batch whose LAST num_decode_seqs sequences are running
-    # sequences contributing one decode row each): rows [0, num_prefill_tokens) are prompt
-    # tokens, the next num_decode_seqs rows are decode tokens whose lengths are context_lens
+    # mixed step (a prefill-form batch whose FIRST num_decode_seqs sequences are running
+    # sequences contributing one decode row each): rows [0, num_decode_seqs) are decode tokens
+    # whose lengths are context_lens, the prompt tokens follow (cu_seqlens_q holds their rows)
     num_decode_seqs: int = 0
     num_prefill_tokens: int = 0
     total_k_tokens: int = 0                       # prefill: sum of context lengths (0 = unknown)

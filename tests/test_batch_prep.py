@@ -16,11 +16,16 @@ def _runner(bs):
     return ModelRunner(as_engine_config(cfg), 0)
 
 
+def _inside(seqs, num_decode):
+    """Order of the sequences inside a batch: the riders (the caller's last ``num_decode``) first."""
+    first_decode = len(seqs) - num_decode
+    return list(seqs[first_decode:]) + list(seqs[:first_decode])
+
+
 def _expected(seqs, num_decode, bs):
     ids, pos, slots, cu_q, cu_k = [], [], [], [0], [0]
-    first_decode = len(seqs) - num_decode
-    for i, s in enumerate(seqs):
-        if i >= first_decode:
+    for i, s in enumerate(_inside(seqs, num_decode)):
+        if i < num_decode:
             start, end = s.num_tokens - 1, s.num_tokens
         else:
             start = s.num_cached_tokens
@@ -62,9 +67,9 @@ def test_prepare_prefill_arrays_match_the_definition():
             assert b.num_prefill_tokens == n - num_decode and b.num_seqs == len(seqs)
             assert b.max_seqlen_k == max(cu_k[i + 1] - cu_k[i] for i in range(len(seqs)))
             first_decode = len(seqs) - num_decode
-            assert b.max_seqlen_q == max(cu_q[i + 1] - cu_q[i] for i in range(first_decode))
+            assert b.max_seqlen_q == max(cu_q[i + 1] - cu_q[i] for i in range(num_decode, len(seqs)))
             assert b.has_prefix            # one sequence has cached tokens
-            for i, s in enumerate(seqs):
+            for i, s in enumerate(_inside(seqs, num_decode)):
                 assert a["block_tables"][i, :len(s.block_table)].tolist() == s.block_table
                 assert (a["block_tables"][i, len(s.block_table):] == -1).all()
             if num_decode:

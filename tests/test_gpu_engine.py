@@ -339,10 +339,15 @@ def test_mixed_prefill_decode_steps_on_gpu(gpu):
     steps = plain.stats.prefill_steps + plain.stats.decode_steps
     plain.exit()
     mixed = LLMEngine(_cfg(max_num_batched_tokens=512, enable_mixed_batches=True,
-                           enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8]))
+                           enforce_eager=False, graph_batch_sizes=[1, 2, 4, 8],
+                           prefill_graph_capture_after=1))
     got = mixed.generate(prompts, sp)["token_ids"]
     assert mixed.scheduler.num_mixed_steps > 0
     assert mixed.stats.prefill_steps + mixed.stats.decode_steps < steps
+    # mixed steps replay captured graphs too (key: token bucket, sequence slots, decode slots)
+    r = mixed.model_runner
+    assert any(k[2] > 0 for k in r.prefill_graphs), list(r.prefill_graphs)
+    assert r.prefill_graph_replays > 0
     bm = mixed.scheduler.block_manager
     assert bm.num_free_blocks == bm.num_blocks
     mixed.exit()
@@ -350,6 +355,12 @@ def test_mixed_prefill_decode_steps_on_gpu(gpu):
     same = sum(int(a == b) for x, y in zip(want, got) for a, b in zip(x, y))
     total = sum(len(x) for x in want)
     assert same / total > 0.9, (same, total)
+    # the same engine with every step launched eagerly: captured mixed steps change nothing
+    eager = LLMEngine(_cfg(max_num_batched_tokens=512, enable_mixed_batches=True, enforce_eager=True))
+    got_eager = eager.generate(prompts, sp)["token_ids"]
+    eager.exit()
+    same = sum(int(a == b) for x, y in zip(got_eager, got) for a, b in zip(x, y))
+    assert same / total > 0.97, (same, total)
 
 
 def test_top_k_top_p_on_gpu_with_graphs_and_sharded_logits(gpu):

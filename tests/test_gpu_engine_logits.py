@@ -38,7 +38,8 @@ def _cfg(geom, **kw):
                         tie_word_embeddings=True, **GEOMETRIES[geom])
     base = dict(model=model, max_num_sequences=8, max_num_batched_tokens=4096, block_size=BS,
                 max_model_length=2048, eos=-1, max_cached_blocks=64, dtype=torch.bfloat16,
-                device="cuda", enforce_eager=True, seed=3, tune_decode_gemms=False)
+                device="cuda", enforce_eager=True, seed=3, tune_decode_gemms=False,
+                prefill_graph_capture_after=1)
     base.update(kw)
     return EngineConfig(**base).validate()
 
