@@ -74,6 +74,8 @@ def make_config(args, model_name: str, world: int) -> EngineConfig:
         dist_backend=os.environ.get("MINIVLLM_DIST_BACKEND", "auto"),
         max_cached_blocks=args.kv_blocks, kv_cache_dtype=args.kv_cache_dtype,
         tp_shard=args.tp_shard if world == 1 else 0,
+        # every step of a phase has the same shape: capture it at its first (warm-up) occurrence
+        prefill_graph_capture_after=1,
         custom_all_reduce=bool(args.tp_shard and args.p2p)).validate()
 
 
