@@ -26,6 +26,9 @@ GEOMETRIES = {
                    num_layers=2),
     # five query heads per KV head, biased QKV projection and no q/k norm (Qwen2.5-style): the
     # attention kernels' transforms run without norm weights
+    # 64-wide heads, four query heads per KV head
+    "16q4kv-d64": dict(hidden_size=1024, num_heads=16, num_kv_heads=4, intermediate_size=2048,
+                       num_layers=2, head_dim=64),
     "40q8kv-bias": dict(hidden_size=1024, num_heads=40, num_kv_heads=8, intermediate_size=2048,
                         num_layers=2, qkv_bias=True),
 }
@@ -34,8 +37,8 @@ REL_TOL_SAME = 0.015      # GPU against GPU through another path (graph / chunke
 
 
 def _cfg(geom, **kw):
-    model = ModelConfig(vocab_size=VOCAB, head_dim=128, max_position=4096, base=1e6,
-                        tie_word_embeddings=True, **GEOMETRIES[geom])
+    model = ModelConfig(**{**dict(vocab_size=VOCAB, head_dim=128, max_position=4096, base=1e6,
+                                  tie_word_embeddings=True), **GEOMETRIES[geom]})
     base = dict(model=model, max_num_sequences=8, max_num_batched_tokens=4096, block_size=BS,
                 max_model_length=2048, eos=-1, max_cached_blocks=64, dtype=torch.bfloat16,
                 device="cuda", enforce_eager=True, seed=3, tune_decode_gemms=False,
