@@ -23,11 +23,14 @@ import torch.nn.functional as F
 from . import group as pg
 from .. import ops
 
-# Below this many rows per chunk the collective is latency-bound and splitting only hurts.  Both
-# values are estimates until measured on a real xGMI node: MINIVLLM_OVERLAP_MIN_CHUNK_TOKENS /
-# MINIVLLM_OVERLAP_MAX_CHUNKS (or ``configure``) override them for a first run; MAX_CHUNKS = 1
-# switches the pipelining off.
-MIN_CHUNK_TOKENS = int(os.environ.get("MINIVLLM_OVERLAP_MIN_CHUNK_TOKENS", 2048))
+# Rows per chunk.  The GEMM side is measured (one MI355X, per-rank o / down shapes of Qwen3-8B at
+# TP = 2, 4, 8, 16384 rows; tools/overlap_chunk_cost_probe.py): chunks of 4096 rows or more cost
+# the GEMMs nothing (-10 % ... +3 %; the 512-deep o projection of TP = 8 +15 % = 10 us), chunks
+# of 2048 rows 25-60 % (the 256-row tiles no longer fill the chip evenly).  The collective side
+# is an estimate until measured on a real xGMI node: MINIVLLM_OVERLAP_MIN_CHUNK_TOKENS /
+# MINIVLLM_OVERLAP_MAX_CHUNKS (or ``configure``) override both; MAX_CHUNKS = 1 switches the
+# pipelining off.
+MIN_CHUNK_TOKENS = int(os.environ.get("MINIVLLM_OVERLAP_MIN_CHUNK_TOKENS", 4096))
 MAX_CHUNKS = int(os.environ.get("MINIVLLM_OVERLAP_MAX_CHUNKS", 4))
 
 

@@ -235,7 +235,7 @@ def _overlap_worker(rank, world, port, q):
         res[n] = row_parallel_linear(xs.contiguous(), ws.contiguous(), bias if rank == 0 else None, n)
     want = x_full @ w_full.T + bias
     ok = all(torch.allclose(v, want, atol=1e-4, rtol=1e-4) for v in res.values())
-    q.put((rank, ok, plan_chunks(100), plan_chunks(16384), plan_chunks(5000)))
+    q.put((rank, ok, plan_chunks(100), plan_chunks(16384), plan_chunks(8192)))
     g.destroy_tensor_parallel()
 
 
