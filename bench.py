@@ -296,10 +296,11 @@ def run_phase(args, phase: str, rank: int, local_rank: int, world: int):
 
 
 def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int, conservative: bool = False,
-                port_shift: int = 0):
+                port_shift: int = 0, limit: int = 0):
     """Run ``phase`` in a child process of this rank (the children of all ranks form the job of
     that phase).  Returns rank 0's result dict, or {'error': ...}.  ``conservative``: the engine's
-    newer multi-rank paths off (MINIVLLM_TP_CONSERVATIVE, see ModelRunner)."""
+    newer multi-rank paths off (MINIVLLM_TP_CONSERVATIVE, see ModelRunner).  ``limit``: seconds
+    after which the child is stopped (0 = the phase's default)."""
     env = dict(os.environ)
     if conservative:
         env["MINIVLLM_TP_CONSERVATIVE"] = "1"
@@ -314,7 +315,7 @@ def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int, conser
     cmd = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
     # the headline (tp) and the long-context phase get the full limit; side results less, so
     # that a stuck one does not hold the JSON line back long
-    limit = args.phase_timeout if phase in ("tp", "l32k") else min(args.phase_timeout, 360)
+    limit = limit or phase_limit(args, phase)
     t0 = time.time()
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     stdout = None
@@ -341,6 +342,56 @@ def spawn_phase(args, phase: str, rank: int, local_rank: int, world: int, conser
             return res
     return {"error": f"{phase} phase printed no result"}
 
+
+def phase_limit(args, phase: str) -> int:
+    return args.phase_timeout if phase in ("tp", "l32k") else min(args.phase_timeout, 360)
+
+
+class JobClock:
+    """Keeps an N > 1 run inside ``--total-timeout``: before each phase after the first, rank 0
+    decides how long the phase may take (what is left of the budget, capped by the phase's own
+    limit) or that it is skipped, and publishes the decision through the key-value store, so
+    that the ranks never disagree about whether a phase runs.  Without a store (it could not be
+    set up) every phase runs with its own limit."""
+
+    MIN_USEFUL_S = 90                            # an engine start alone takes about that long
+
+    def __init__(self, args, rank: int, world: int):
+        self.args, self.rank, self.t0, self.store = args, rank, time.time(), None
+        try:
+            import datetime
+            from torch.distributed import TCPStore
+            self.store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
+                                  int(os.environ.get("MASTER_PORT", args.port)) + 555, world,
+                                  rank == 0,
+                                  timeout=datetime.timedelta(seconds=args.phase_timeout + 90))
+        except Exception as e:
+            print(f"[bench] rank {rank}: no key-value store between the ranks ({e!r}): no retry "
+                  f"of a failed phase, no overall time limit", file=sys.stderr, flush=True)
+
+    def agree(self, key: str, value) -> str:
+        """Rank 0's ``value`` (a string), on every rank; None without a store."""
+        if self.store is None:
+            return None
+        try:
+            if self.rank == 0:
+                self.store.set(key, str(value))
+            return self.store.get(key).decode()
+        except Exception as e:
+            print(f"[bench] rank {self.rank}: store failed on {key!r} ({e!r})", file=sys.stderr,
+                  flush=True)
+            self.store = None
+            return None
+
+    def limit_for(self, phase: str, tag: str = "") -> int:
+        """Seconds the phase may run (the same number on every rank); 0 = skip it."""
+        own = phase_limit(self.args, phase)
+        left = int(self.args.total_timeout - (time.time() - self.t0)) - 20
+        got = self.agree(f"limit_{phase}{tag}", min(own, left) if left >= self.MIN_USEFUL_S else 0)
+        return own if got is None else int(got)
+
+
+SKIPPED = {"error": "skipped: the run's overall time limit (--total-timeout) was nearly used up"}
 
 _RESULT_OUT = None
 
@@ -493,6 +544,9 @@ def main():
                     help="with N > 1, skip the TP phase that uses the peer-to-peer all-reduce kernel")
     ap.add_argument("--phase-timeout", type=int, default=600,
                     help="time limit in seconds of one phase (N > 1)")
+    ap.add_argument("--total-timeout", type=int, default=1500,
+                    help="N > 1: side phases are shortened or skipped so that the whole run ends "
+                         "within about this many seconds even if phases hang")
     ap.add_argument("--tp-shard", type=int, default=0,
                     help="ONE GPU: run rank 0's shard of an N-way tensor-parallel engine with every "
                          "collective issued through a single-member RCCL group (per-rank compute + "
@@ -555,34 +609,28 @@ def main():
     # ---- N > 1: orchestrate one child per phase --------------------------------------
     if rank == 0:
         print(f"[bench] {world} ranks up, starting the tensor-parallel phase", file=sys.stderr, flush=True)
+    clock = JobClock(args, rank, world)
+
+    def side_phase(phase):
+        limit = clock.limit_for(phase)
+        return spawn_phase(args, phase, rank, local_rank, world, limit=limit) if limit else dict(SKIPPED)
+
     # headline first: whatever happens to the side phases, its number exists by then
     tp = None if args.no_tp else spawn_phase(args, "tp", rank, local_rank, world)
     tp_first = None
-    if not args.no_tp:                           # every rank votes (ranks > 0 hold no result)
+    if not args.no_tp:
         # a failed tensor-parallel phase is tried once more with the engine's newer multi-rank
-        # paths off.  Rank 0's verdict decides for everybody (only its child prints the numbers),
-        # published through a key-value store next to the launcher's rendezvous port.
-        retry = False
-        try:
-            import datetime
-            from torch.distributed import TCPStore
-            store = TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"),
-                             int(os.environ.get("MASTER_PORT", args.port)) + 555, world, rank == 0,
-                             timeout=datetime.timedelta(seconds=args.phase_timeout + 90))
-            if rank == 0:
-                store.set("tp_retry", "1" if not phase_ok(tp) else "0")
-            retry = store.get("tp_retry") == b"1"
-        except Exception as e:                   # no vote, no retry
-            print(f"[bench] rank {rank}: retry vote unavailable ({e!r})", file=sys.stderr, flush=True)
-        if retry:
-            tp_first = tp
-            tp = spawn_phase(args, "tp", rank, local_rank, world, conservative=True, port_shift=37)
+        # paths off.  Rank 0's verdict decides for everybody (only its child prints the numbers).
+        if clock.agree("tp_retry", "0" if phase_ok(tp) else "1") == "1":
+            limit = clock.limit_for("tp", "_retry")
+            if limit:
+                tp_first = tp
+                tp = spawn_phase(args, "tp", rank, local_rank, world, conservative=True,
+                                 port_shift=37, limit=limit)
     want_long = args.long_context == "on" or (args.long_context == "auto" and world == 8)
-    long_ctx = (spawn_phase(args, "l32k", rank, local_rank, world)
-                if want_long and not args.no_tp else None)
-    tpc = (None if args.no_tp or args.no_p2p or world not in (2, 4, 8)
-           else spawn_phase(args, "tpc", rank, local_rank, world))
-    dp = None if args.no_dp else spawn_phase(args, "dp", rank, local_rank, world)
+    long_ctx = side_phase("l32k") if want_long and not args.no_tp else None
+    tpc = None if args.no_tp or args.no_p2p or world not in (2, 4, 8) else side_phase("tpc")
+    dp = None if args.no_dp else side_phase("dp")
     if rank != 0:
         return
     out, good = assemble_multi_gpu(args, world, dp, tp, tpc, metric, base, cfg_common, long_ctx)

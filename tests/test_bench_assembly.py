@@ -77,3 +77,33 @@ def test_prefill_only_mode_has_a_headline():
         r["main"].pop(k)
     out, good = _assemble(None, r, None)
     assert good and out["value"] == 94000.0 and out["ms_per_step"] == 170.0
+
+
+def test_overall_time_budget_of_a_multi_gpu_run(monkeypatch):
+    """Rank 0 decides what a side phase may still take; all ranks read the same number; a phase
+    with too little left is skipped; without a store every phase keeps its own limit."""
+    import argparse
+    import time
+
+    class FakeStore(dict):
+        def set(self, k, v):
+            self[k] = v.encode()
+
+        def get(self, k):
+            return self[k]
+
+    args = argparse.Namespace(phase_timeout=600, total_timeout=1000, port=1)
+
+    def clock(rank, store, started_ago):
+        c = bench.JobClock.__new__(bench.JobClock)
+        c.args, c.rank, c.store, c.t0 = args, rank, store, time.time() - started_ago
+        return c
+
+    store = FakeStore()
+    assert clock(0, store, 100).limit_for("l32k") == 600         # plenty left: the phase's own limit
+    assert clock(1, store, 500).limit_for("l32k") == 600         # rank 1 takes rank 0's number
+    assert clock(0, store, 700).limit_for("tpc") in (279, 280)   # what is left, minus the reserve
+    assert clock(0, store, 900).limit_for("dp") == 0             # not worth starting
+    assert clock(1, store, 0).limit_for("dp") == 0
+    assert clock(0, None, 990).limit_for("dp") == 360            # no store: no overall limit
+    assert clock(0, store, 0).agree("tp_retry", "1") == "1" and clock(1, store, 0).agree("tp_retry", "0") == "1"
