@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--q-rope", action="store_true",
                     help="prefill: q-norm + RoPE of the Q rows inside the kernel (the engine's pure "
                          "prefill steps)")
+    ap.add_argument("--fused-store", action="store_true",
+                    help="decode: the engine's form (raw q / k / v of the new token in; the kernel "
+                         "norms, rotates and stores them itself)")
     a = ap.parse_args()
     eb = 1 if a.kv_fp8 else 2
     q8 = (lambda c: c.to(torch.float8_e4m3fn)) if a.kv_fp8 else (lambda c: c)
@@ -88,7 +91,16 @@ def main():
             q = torch.randn(B, hq, d, device="cuda", dtype=torch.bfloat16)
             ctx = torch.full((B,), S, device="cuda", dtype=torch.int32)
             bt = torch.arange(B * nblk, device="cuda", dtype=torch.int32).view(B, nblk)
-            t = timeit(lambda: hip.paged_attention_decode(q, kc, vc, bt, ctx, scale, S), a.iters)
+            new_kv = None
+            if a.fused_store:
+                qkv = torch.randn(B, (hq + 2 * hkv) * d, device="cuda", dtype=torch.bfloat16)
+                q = qkv[:, :hq * d].view(B, hq, d)
+                inv = 1.0 / (1e6 ** (torch.arange(0, d, 2, device="cuda").float() / d))
+                ang = torch.arange(S, device="cuda").float()[:, None] * inv[None]
+                w = lambda: torch.rand(d, device="cuda", dtype=torch.bfloat16) + 0.5
+                new_kv = (qkv[:, hq * d:(hq + hkv) * d].view(B, hkv, d), qkv[:, (hq + hkv) * d:].view(B, hkv, d),
+                          torch.cat([ang.cos(), ang.sin()], 1).contiguous(), w(), w(), 1e-6)
+            t = timeit(lambda: hip.paged_attention_decode(q, kc, vc, bt, ctx, scale, S, new_kv=new_kv), a.iters)
             by = 2 * B * S * hkv * d * eb
             print(f"decode  B={B} ctx={S}: {t*1e3:8.3f} ms  {by/t/1e12:6.2f} TB/s KV stream", flush=True)
             del kc, vc, q
