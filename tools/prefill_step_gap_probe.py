@@ -22,7 +22,7 @@ for _ in range(4):
     eng.step()
 r = eng.model_runner
 marks = {}
-for name in ("prepare_prefill", "_upload_prefill"):
+for name in ("prepare_prefill", "_upload_prefill", "_fill_prefill_graph_inputs", "_run_prefill_graph"):
     fn = getattr(r, name)
     def wrap(*a, _fn=fn, _n=name, **k):
         t = time.perf_counter(); out = _fn(*a, **k); marks.setdefault(_n, []).append(time.perf_counter() - t); return out
@@ -36,15 +36,19 @@ def wpost(*a, **k):
     t = time.perf_counter(); out = post(*a, **k); marks.setdefault("postprocess", []).append(time.perf_counter() - t); return out
 eng.scheduler.postprocess = wpost
 torch.cuda.synchronize()
+PROFILE = os.environ.get("CPROFILE") == "1"      # cProfile roughly doubles the host times
 pr = cProfile.Profile()
 t0 = time.perf_counter()
-pr.enable()
+if PROFILE:
+    pr.enable()
 for _ in range(8):
     eng.step()
-pr.disable()
+if PROFILE:
+    pr.disable()
 torch.cuda.synchronize()
 print(f"step {1e3 * (time.perf_counter() - t0) / 8:.2f} ms")
 for k, v in marks.items():
-    print(f"  {k:16s} {1e6 * sum(v) / len(v):8.1f} us per call ({len(v)} calls)")
-pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
+    print(f"  {k:28s} {1e6 * sum(v) / len(v):8.1f} us per call ({len(v)} calls)")
+if PROFILE:
+    pstats.Stats(pr).sort_stats("cumulative").print_stats(28)
 eng.exit()
