@@ -206,7 +206,10 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
     if args.mode in ("both", "prefill"):
         per_step = max(1, min(args.prefill_tokens // S, B))
         sp = SamplingParams(temperature=0.6, max_tokens=1, ignore_eos=True)
-        for p in prompts(per_step * (W + K), S):
+        # one step more than is timed: consecutive prefill steps are launched one ahead, so a step
+        # is in flight when the window opens (timer_start drains it) and the last timed call
+        # launches one that timer_stop drains: the window holds exactly K steps of GPU work
+        for p in prompts(per_step * (W + K + 1), S):
             eng.add_prompt(p, sp)
         for _ in range(W):
             _, n, is_prefill = eng.step()
@@ -231,7 +234,8 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
         sp = SamplingParams(temperature=0.6, max_tokens=W + K + 4, ignore_eos=True)
         for p in prompts(B, S):
             eng.add_prompt(p, sp)
-        while eng.scheduler.waiting or eng.scheduler.prefilling:   # untimed: prefill all B prompts
+        while (eng.scheduler.waiting or eng.scheduler.prefilling      # untimed: prefill all B prompts
+               or eng.model_runner.has_prefill_ahead()):
             _, _, is_prefill = eng.step()
             assert is_prefill
         for _ in range(W):

@@ -220,6 +220,10 @@ class EngineConfig:
     # post-processes; single-rank engines with graph-replayed decode steps only
     # (ModelRunner._can_prelaunch; MINIVLLM_NO_PRELAUNCH=1 switches it off)
     decode_prelaunch: bool = True
+    # consecutive pure prefill steps: admit, prepare and (when the step's graph exists) enqueue
+    # step n + 1 before reading step n's tokens back (Scheduler.schedule_prefill_ahead,
+    # ModelRunner.run(next_prefill=...)); MINIVLLM_NO_PRELAUNCH=1 switches it off as well
+    prefill_prelaunch: bool = True
     # tuning knobs of the multi-GPU path that have no measurement on real xGMI links behind them
     # yet (None = module default, also settable through the environment, see the modules):
     # size above which the peer-to-peer all-reduce switches from one-shot to two-shot, how long

@@ -198,6 +198,26 @@ class LLMEngine:
                 finished = self.scheduler.postprocess(seqs, token_ids)
                 self._drop_stale_prelaunch()
                 return ([(s.seq_id, s.completion_token_ids) for s in finished], len(seqs), False)
+        ahead_fn = self.scheduler.schedule_prefill_ahead if self.cfg.prefill_prelaunch else None
+        if runner.has_prefill_ahead():
+            # the previous prefill step admitted (and possibly launched) this one: its sequences
+            # are in the scheduler's running queue already, so it has to be the next step.  A
+            # sequence that was aborted meanwhile just loses its token.
+            ahead, num_tokens = runner.prefill_ahead_info()
+            alive = [i for i, s in enumerate(ahead) if s.status == SequenceStatus.RUNNING]
+            if not alive:
+                runner.drop_prefill_ahead()
+            else:
+                self._check_workers()
+                self._step_seq += 1
+                self._in_step = self._step_seq
+                try:
+                    token_ids = runner.run_prefill_ahead(next_prefill=ahead_fn)
+                finally:
+                    self._in_step = 0
+                finished = self.scheduler.postprocess([ahead[i] for i in alive],
+                                                      [token_ids[i] for i in alive])
+                return ([(s.seq_id, s.completion_token_ids) for s in finished], num_tokens, True)
         seqs, is_prefill = self.scheduler.schedule()
         if not seqs:
             if not self.scheduler.is_finished():
@@ -216,7 +236,8 @@ class LLMEngine:
         self._in_step = self._step_seq
         try:
             ahead_ok = not is_prefill and self.scheduler.next_decode_step_is_plain()
-            token_ids = self.model_runner.run(seqs, is_prefill, riders, allow_prelaunch=ahead_ok)
+            token_ids = self.model_runner.run(seqs, is_prefill, riders, allow_prelaunch=ahead_ok,
+                                              next_prefill=ahead_fn if is_prefill and not riders else None)
         finally:
             self._in_step = 0
         finished = self.scheduler.postprocess(seqs, token_ids)

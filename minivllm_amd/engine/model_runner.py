@@ -122,7 +122,8 @@ class ModelRunner:
             # launched ahead on the workers, plain all-reduce in front of every norm, prefill
             # graphs only for the shapes captured at start-up
             import dataclasses
-            self.cfg = cfg = dataclasses.replace(cfg, decode_prelaunch=False, prefill_graph_lazy=False,
+            self.cfg = cfg = dataclasses.replace(cfg, decode_prelaunch=False, prefill_prelaunch=False,
+                                                 prefill_graph_lazy=False,
                                                  scatter_norm_min_rows=1 << 30)
         self.rank = rank
         self.world_size = cfg.world_size       # processes of this engine
@@ -385,6 +386,7 @@ class ModelRunner:
                            for _ in range(2)]
         self._tok_flip = 0
         self._spec = None                        # decode step launched ahead, not yet collected
+        self._pf_spec = None                     # prefill step admitted ahead, not yet collected
         self._dec_dev = torch.zeros(self._dec_words, dtype=torch.int32, device=self.device)
         self._pre_host = None
         self._pre_dev = None
@@ -430,7 +432,10 @@ class ModelRunner:
                             ("block_tables", smax * MB)):
                 self._pg_off[name] = (off, n)
                 off += (n + 3) // 4 * 4
-            self._pg_host = torch.zeros(off, dtype=torch.int32, pin_memory=True)
+            # two pinned staging blocks used alternately, as for decode: with a prefill step
+            # launched ahead the host fills step n + 1's block while step n's upload may be pending
+            self._pg_hosts = [torch.zeros(off, dtype=torch.int32, pin_memory=True) for _ in range(2)]
+            self._pg_host, self._pg_flip = self._pg_hosts[0], 0
             self._pg_dev = torch.zeros(off, dtype=torch.int32, device=self.device)
 
     def _ensure_prefill_buffers(self, words: int) -> None:
@@ -487,6 +492,7 @@ class ModelRunner:
             return
         self._exited = True
         self._spec = None
+        self._pf_spec = None
         if self.on_gpu and not peers_dead:
             torch.cuda.synchronize()
             try:
@@ -736,14 +742,18 @@ class ModelRunner:
 
     # ================================================================== run
     def run(self, seqs: Seq[Sequence], is_prefill: bool, num_decode: int = 0,
-            allow_prelaunch: bool = False) -> Optional[List[int]]:
+            allow_prelaunch: bool = False, next_prefill=None) -> Optional[List[int]]:
         """Rank 0 entry point for one step; returns the sampled token per sequence.
         ``num_decode`` > 0 (prefill steps only): the last that many sequences decode.
         ``allow_prelaunch`` (decode steps): the caller guarantees that the NEXT step is a plain
         decode step of the same sequences (nobody crosses a KV-block edge, nothing waits to be
         admitted), so that step may be launched before this one's tokens are read back; the
-        caller then collects it with ``run_prelaunched``."""
-        assert self._spec is None, "a step launched ahead must be collected first"
+        caller then collects it with ``run_prelaunched``.
+        ``next_prefill`` (pure prefill steps): a callable that admits and returns the sequences
+        of the prefill step after this one, or [] (``Scheduler.schedule_prefill_ahead``); that
+        step is then prepared, and where possible launched, before this one's tokens are read
+        back, and the caller must collect it with ``run_prefill_ahead``."""
+        assert self._spec is None and self._pf_spec is None, "a step launched ahead must be collected first"
         if is_prefill:
             self._decode_prev = None
             batch = self.prepare_prefill(seqs, num_decode)
@@ -752,6 +762,8 @@ class ModelRunner:
         self.step_counter += 1
         batch.step = self.step_counter
         batch.prelaunch = allow_prelaunch and self._can_prelaunch(batch)
+        if is_prefill and next_prefill is not None and num_decode == 0:
+            return self._run_prefill_with_lookahead(batch, next_prefill, self._PG_KEY_UNSET)
         if self.world_size > 1 and self.rank == 0:
             self.channel.send("run_batch", batch.scalars(), batch.arrays)
         with torch.inference_mode(), trace_range("prefill_step" if is_prefill else "decode_step"):
@@ -763,6 +775,95 @@ class ModelRunner:
                 self._last_tokens = out
                 return out
             return self.execute(batch)
+
+    # --------------------------------------------------- prefill launched one step ahead
+    # Between two prefill steps the GPU otherwise idles while the host reads the samples back,
+    # retires the sequences, admits the next ones, builds their batch arrays and replays the
+    # graph (~0.4 ms: 2.5 % of a 16k-token Qwen3-0.6B step, more of the 1-4 ms steps a server
+    # sees).  None of that needs the running step's samples when the next step is made of
+    # sequences that are still waiting: they are admitted while the step runs
+    # (``Scheduler.schedule_prefill_ahead``), their inputs go up behind it (second pinned
+    # staging block; the device-side input buffer is only written in stream order, after the
+    # running graph has read it) and their graph is replayed behind that; only then does the
+    # host wait for the running step's tokens, whose copy to the host was enqueued before the
+    # next graph could overwrite the graph's output buffer.  A step whose shape has no graph yet
+    # (it has to be captured, or runs eagerly) is prepared ahead but executed by the next call.
+    # Tensor-parallel workers need nothing new: they execute the batches in the order rank 0
+    # sends them and never wait for tokens.
+    _PG_KEY_UNSET = object()
+
+    def _prefill_can_go_ahead(self, b: Batch, key) -> bool:
+        if not self.cfg.prefill_prelaunch or "top_k" in b.arrays or b.num_decode_seqs:
+            return False
+        if os.environ.get("MINIVLLM_NO_PRELAUNCH") == "1":
+            return False
+        return (key is not None and key in self.prefill_graphs) if self.on_gpu else True
+
+    def _enqueue_prefill_step(self, b: Batch, key) -> torch.Tensor:
+        """Send the batch to the workers and enqueue the step on this rank without waiting for
+        anything; returns the device tensor its tokens land in."""
+        if self.world_size > 1 and self.rank == 0:
+            self.channel.send("run_batch", b.scalars(), b.arrays)
+        tokens, logits = self._enqueue_prefill(b, key if self.on_gpu else None)
+        reset_context()
+        self._last_step_logits = logits
+        return tokens
+
+    def _run_prefill_with_lookahead(self, b: Batch, next_prefill, key, launched=None) -> List[int]:
+        """The step ``b`` (already on the device when ``launched`` = its pending token read),
+        with the step after it admitted, prepared and - if its graph exists - launched before
+        this one's tokens are waited for."""
+        with torch.inference_mode(), trace_range("prefill_step"):
+            if launched is None:
+                if key is self._PG_KEY_UNSET:
+                    key = self._prefill_graph_key(b)
+                if not self._prefill_can_go_ahead(b, key):
+                    # runs the ordinary way (eager, or captured now); nothing is launched behind a
+                    # step that may synchronise, but the look-ahead stays available to the next one
+                    if self.world_size > 1 and self.rank == 0:
+                        self.channel.send("run_batch", b.scalars(), b.arrays)
+                    return self.execute(b, pg_key=key)
+                tokens_dev = self._enqueue_prefill_step(b, key)
+                launched = self._read_tokens_async(tokens_dev, b.num_seqs)
+            nxt = next_prefill() if next_prefill is not None else []
+            if nxt:
+                nb = self.prepare_prefill(nxt, 0)
+                nkey = self._prefill_graph_key(nb)
+                spec = dict(seqs=nxt, batch=nb, key=nkey, pending=None,
+                            num_tokens=sum(s.num_scheduled_prefill_tokens for s in nxt))
+                if self._prefill_can_go_ahead(nb, nkey):
+                    self.step_counter += 1
+                    nb.step = self.step_counter
+                    spec["pending"] = self._read_tokens_async(self._enqueue_prefill_step(nb, nkey),
+                                                              nb.num_seqs)
+                self._pf_spec = spec
+            out = self._finish_read(launched)
+            self._last_tokens = None
+            return out
+
+    def has_prefill_ahead(self) -> bool:
+        return self._pf_spec is not None
+
+    def prefill_ahead_info(self):
+        """(sequences, prompt tokens computed) of the prefill step admitted ahead."""
+        return self._pf_spec["seqs"], self._pf_spec["num_tokens"]
+
+    def run_prefill_ahead(self, next_prefill=None) -> List[int]:
+        """Collect (or, if it could not be launched ahead, run) the prefill step admitted ahead;
+        returns one token per sequence of ``prefill_ahead_info()``."""
+        spec, self._pf_spec = self._pf_spec, None
+        b = spec["batch"]
+        self._decode_prev = None
+        if spec["pending"] is None:
+            self.step_counter += 1
+            b.step = self.step_counter
+        return self._run_prefill_with_lookahead(b, next_prefill, spec["key"], launched=spec["pending"])
+
+    def drop_prefill_ahead(self) -> None:
+        """Forget the step admitted ahead (every sequence of it has left)."""
+        if self._pf_spec is not None and self._pf_spec["pending"] is not None and self.on_gpu:
+            torch.cuda.synchronize()
+        self._pf_spec = None
 
     # ---------------------------------------------------- decode launched one step ahead
     # The GPU otherwise idles between two decode steps while the host reads the tokens back,
@@ -993,24 +1094,30 @@ class ModelRunner:
                     block_tables=self._dec_view(d, "block_tables", n * MB).view(n, MB))
 
     # -------------------------------------------------------------- execute
-    def execute(self, b: Batch, warmup: bool = False) -> Optional[List[int]]:
-        pg_key = self._prefill_graph_key(b) if b.is_prefill and not warmup else None
+    def _enqueue_prefill(self, b: Batch, pg_key, warmup: bool = False):
+        """Enqueue one prefill step (graph replay, first run + capture, or eager launches);
+        returns (device tensor of the sampled tokens, the step's logits)."""
         if pg_key is not None:
-            tokens, logits = self._run_prefill_graph(b, pg_key)
-        elif b.is_prefill:
-            t = self._upload_prefill(b)
-            set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
-                        max_seqlen_q=b.max_seqlen_q, max_seqlen_k=b.max_seqlen_k,
-                        slot_mapping=None if warmup else t["slot_mapping"],
-                        block_tables=None if warmup else t["block_tables"],
-                        positions=t["positions"], num_seqs=b.num_seqs, has_prefix=b.has_prefix,
-                        num_decode_seqs=b.num_decode_seqs, num_prefill_tokens=b.num_prefill_tokens,
-                        context_lens=t["context_lens"] if b.num_decode_seqs else None,
-                        max_context_len=b.max_context_len, total_k_tokens=b.num_prefill_k_tokens,
-                        prefill_items=None if warmup else t["prefill_items"],
-                        positions_in_context=True)
-            tokens = self._forward_and_sample(t)
-            logits = self._last_logits
+            return self._run_prefill_graph(b, pg_key)
+        t = self._upload_prefill(b)
+        set_context(True, cu_seqlens_q=t["cu_seqlens_q"], cu_seqlens_k=t["cu_seqlens_k"],
+                    max_seqlen_q=b.max_seqlen_q, max_seqlen_k=b.max_seqlen_k,
+                    slot_mapping=None if warmup else t["slot_mapping"],
+                    block_tables=None if warmup else t["block_tables"],
+                    positions=t["positions"], num_seqs=b.num_seqs, has_prefix=b.has_prefix,
+                    num_decode_seqs=b.num_decode_seqs, num_prefill_tokens=b.num_prefill_tokens,
+                    context_lens=t["context_lens"] if b.num_decode_seqs else None,
+                    max_context_len=b.max_context_len, total_k_tokens=b.num_prefill_k_tokens,
+                    prefill_items=None if warmup else t["prefill_items"],
+                    positions_in_context=True)
+        tokens = self._forward_and_sample(t)
+        return tokens, self._last_logits
+
+    def execute(self, b: Batch, warmup: bool = False, pg_key=_PG_KEY_UNSET) -> Optional[List[int]]:
+        if b.is_prefill:
+            if pg_key is self._PG_KEY_UNSET:
+                pg_key = self._prefill_graph_key(b) if not warmup else None
+            tokens, logits = self._enqueue_prefill(b, pg_key, warmup)
         else:
             B = b.num_seqs
             bucket = self._graph_bucket(B)
@@ -1332,6 +1439,8 @@ class ModelRunner:
         pad = db - Bd                      # unused decode slots: one row each, length 0
         T = Bd + b.num_prefill_tokens      # real rows of the batch (riders, then prompts)
         from minivllm_amd.ops import hip
+        self._pg_flip ^= 1
+        self._pg_host = self._pg_hosts[self._pg_flip]
         host = self._pg_host.numpy()
         for name, fill in (("input_ids", 0), ("positions", 0), ("slot_mapping", -1)):
             o, _ = self._pg_off[name]

@@ -72,6 +72,9 @@ class Scheduler:
         # it may update its batch arrays incrementally)
         self._decode_batch: Optional[List[Sequence]] = None
         self._plain_decode_steps = 0
+        # sequence ids whose partial prefill chunk of the running step has been accounted for
+        # already (schedule_prefill_ahead): postprocess skips each of them once
+        self._advanced_early: set = set()
 
     def is_finished(self) -> bool:
         return not self.waiting and not self.running and not self.prefilling
@@ -99,63 +102,14 @@ class Scheduler:
 
     # ------------------------------------------------------------- schedule
     def schedule(self) -> Tuple[List[Sequence], bool]:
-        scheduled: List[Sequence] = []
-        num_tokens = 0
-        bm = self.block_manager
-
-        budget = self.max_num_batched_tokens
         self.last_num_decode = 0
-        if self.enable_mixed_batches:                   # leave room for the riders
-            budget = max(budget - len(self.running), min(budget, self.block_size))
-        # phase 0: continue sequences whose prefill was cut by an earlier step's budget
-        while self.prefilling and len(scheduled) < self.max_num_sequences and num_tokens < budget:
-            seq = self.prefilling[0]
-            take = min(len(seq) - seq.num_cached_tokens, budget - num_tokens)
-            seq.prefill_end = seq.num_cached_tokens + take
-            scheduled.append(seq)
-            num_tokens += take
-            if seq.prefill_end < len(seq):
-                break                                   # budget exhausted, still not complete
-            self.prefilling.popleft()
-            self.running.append(seq)
-
-        # phase 1: admit waiting sequences (prefill) in arrival order.  Nothing new is admitted
-        # while an older sequence is still incomplete after this step: a newcomer could hit its
-        # prefix-cache blocks before their KV exists.
-        while (self.waiting and not self.prefilling and len(scheduled) < self.max_num_sequences):
-            if not scheduled and self._defer_prefill():
-                break
-            seq = self.waiting[0]
-            fits = num_tokens + len(seq) <= budget
-            # a cut sequence gets at least one KV block worth of tokens now, or waits
-            room = budget - num_tokens >= min(len(seq), self.block_size)
-            if not fits and scheduled and not (self.enable_chunked_prefill and room):
-                break
-            if not bm.can_allocate(seq):
-                break
-            if len(self.running) >= self.max_num_sequences:
-                break
-            self.waiting.popleft()
-            bm.allocate(seq)
-            seq.status = SequenceStatus.RUNNING
-            todo = len(seq) - seq.num_cached_tokens
-            take = todo
-            if self.enable_chunked_prefill:
-                take = min(todo, budget - num_tokens)
-            # without chunking an over-long sequence (grew while running, then preempted) goes
-            # through alone rather than stall forever
-            seq.prefill_end = seq.num_cached_tokens + take
-            scheduled.append(seq)
-            num_tokens += take
-            if seq.prefill_end < len(seq):
-                self.prefilling.append(seq)
-                break
-            self.running.append(seq)
+        scheduled, num_tokens = self._schedule_prefill()
         if scheduled:
             self._decode_batch = None
             if self.enable_mixed_batches:
                 self._add_decode_riders(scheduled, num_tokens)
             return scheduled, True
+        bm = self.block_manager
 
         # phase 2: one token for every running sequence, oldest first
         if (self._decode_batch is not None and self._plain_decode_steps > 0 and not self.waiting
@@ -208,6 +162,85 @@ class Scheduler:
         else:
             self._decode_batch = None
         return scheduled, False
+
+    def _schedule_prefill(self) -> Tuple[List[Sequence], int]:
+        """The sequences of a prefill step (and the prompt tokens it computes), [] when nothing
+        is to be prefetched now."""
+        scheduled: List[Sequence] = []
+        num_tokens = 0
+        bm = self.block_manager
+        budget = self.max_num_batched_tokens
+        if self.enable_mixed_batches:                   # leave room for the riders
+            budget = max(budget - len(self.running), min(budget, self.block_size))
+        # phase 0: continue sequences whose prefill was cut by an earlier step's budget
+        while self.prefilling and len(scheduled) < self.max_num_sequences and num_tokens < budget:
+            seq = self.prefilling[0]
+            take = min(len(seq) - seq.num_cached_tokens, budget - num_tokens)
+            seq.prefill_end = seq.num_cached_tokens + take
+            scheduled.append(seq)
+            num_tokens += take
+            if seq.prefill_end < len(seq):
+                break                                   # budget exhausted, still not complete
+            self.prefilling.popleft()
+            self.running.append(seq)
+
+        # phase 1: admit waiting sequences (prefill) in arrival order.  Nothing new is admitted
+        # while an older sequence is still incomplete after this step: a newcomer could hit its
+        # prefix-cache blocks before their KV exists.
+        while (self.waiting and not self.prefilling and len(scheduled) < self.max_num_sequences):
+            if not scheduled and self._defer_prefill():
+                break
+            seq = self.waiting[0]
+            fits = num_tokens + len(seq) <= budget
+            # a cut sequence gets at least one KV block worth of tokens now, or waits
+            room = budget - num_tokens >= min(len(seq), self.block_size)
+            if not fits and scheduled and not (self.enable_chunked_prefill and room):
+                break
+            if not bm.can_allocate(seq):
+                break
+            if len(self.running) >= self.max_num_sequences:
+                break
+            self.waiting.popleft()
+            bm.allocate(seq)
+            seq.status = SequenceStatus.RUNNING
+            todo = len(seq) - seq.num_cached_tokens
+            take = todo
+            if self.enable_chunked_prefill:
+                take = min(todo, budget - num_tokens)
+            # without chunking an over-long sequence (grew while running, then preempted) goes
+            # through alone rather than stall forever
+            seq.prefill_end = seq.num_cached_tokens + take
+            scheduled.append(seq)
+            num_tokens += take
+            if seq.prefill_end < len(seq):
+                self.prefilling.append(seq)
+                break
+            self.running.append(seq)
+        return scheduled, num_tokens
+
+    # ------------------------------------------------ prefill steps launched ahead
+    def schedule_prefill_ahead(self) -> List[Sequence]:
+        """While a prefill step is still on the device (``postprocess`` has not run for it): the
+        sequences of the prefill step that follows, or [] when the next step is not a prefill
+        step or cannot be decided yet.  Nothing a prefill step's make-up depends on needs the
+        tokens the running step will sample: newcomers take blocks that are free now, a sequence
+        of the running step that finishes only gives blocks and slots back, and a prompt the
+        running step has cut at its token budget continues where that chunk ends - its
+        bookkeeping for the running step is done here, early, and ``postprocess`` then skips it
+        once.  Steps with decode riders are left to ``schedule``.  The caller must run the
+        returned step next."""
+        if self.enable_mixed_batches or not (self.waiting or self.prefilling):
+            return []
+        if self.prefilling:
+            cut = self.prefilling[0]
+            if cut.prefill_end is None or cut.seq_id in self._advanced_early:
+                return []                           # not part of the step that is running
+            cut.num_cached_tokens, cut.prefill_end = cut.prefill_end, None
+            self._advanced_early.add(cut.seq_id)
+        scheduled, _ = self._schedule_prefill()
+        if scheduled:
+            self._decode_batch = None
+        return scheduled
 
     # ------------------------------------------------ decode steps launched ahead
     def next_decode_step_is_plain(self) -> bool:
@@ -293,6 +326,7 @@ class Scheduler:
         if not found:
             return False
         self._decode_batch = None
+        self._advanced_early.discard(seq.seq_id)
         if seq.block_table:
             if in_prefill or seq.prefill_end is not None:
                 # prefill incomplete, or its step never reached postprocess
@@ -310,6 +344,9 @@ class Scheduler:
     def postprocess(self, seqs: List[Sequence], token_ids: List[int]) -> List[Sequence]:
         finished = []
         for seq, token_id in zip(seqs, token_ids):
+            if seq.seq_id in self._advanced_early:
+                self._advanced_early.discard(seq.seq_id)     # a cut prompt, advanced ahead of time
+                continue
             if seq.prefill_end is not None:
                 end, seq.prefill_end = seq.prefill_end, None
                 if end < seq.num_tokens:

@@ -363,6 +363,39 @@ def test_mixed_prefill_decode_steps_on_gpu(gpu):
     assert same / total > 0.97, (same, total)
 
 
+def test_prefill_steps_launched_ahead_replay_graphs_and_change_nothing(gpu):
+    """A queue of prompts that takes many prefill steps (token budget 512: most steps end in a
+    cut prompt): with the look-ahead every step after a shape's capture is enqueued behind the
+    running one before its tokens are read; the tokens must be those of the engine that reads
+    every step's tokens back first (same graphs, same batches: same bits)."""
+    from minivllm_amd.engine.llm_engine import LLMEngine
+    prompts = _prompts(40, lo=30, hi=400, seed=23)
+    sp = [SamplingParams(temperature=0, max_tokens=1 + (i % 3), ignore_eos=True)
+          for i in range(len(prompts))]
+
+    def go(ahead):
+        eng = LLMEngine(_cfg(max_num_batched_tokens=512, enforce_eager=False,
+                             graph_batch_sizes=[1, 2, 4, 8], prefill_graph_capture_after=1,
+                             prefill_prelaunch=ahead))
+        seqs = [eng.add_prompt(p, q) for p, q in zip(prompts, sp)]
+        done, launched = {}, 0
+        while not eng.is_finished():
+            done.update(eng.step()[0])
+            spec = eng.model_runner._pf_spec
+            launched += spec is not None and spec["pending"] is not None
+        r = eng.model_runner
+        replays = r.prefill_graph_replays
+        bm = eng.scheduler.block_manager
+        assert bm.num_free_blocks == bm.num_blocks
+        eng.exit()
+        return [done[s.seq_id] for s in seqs], launched, replays
+
+    want, n0, _ = go(False)
+    got, n1, replays = go(True)
+    assert n0 == 0 and n1 >= 5 and replays >= n1
+    assert got == want
+
+
 def test_top_k_top_p_on_gpu_with_graphs_and_sharded_logits(gpu):
     """Restricted sampling reads the step's logits out of the replayed graphs' static buffers;
     with two TP ranks the rows concerned are gathered over the vocabulary shards.  top_k=1 /

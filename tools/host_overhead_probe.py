@@ -17,7 +17,7 @@ rng = np.random.default_rng(0)
 sp = SamplingParams(temperature=0.6, max_tokens=K + 8, ignore_eos=True)
 for p in rng.integers(0, 150000, size=(B, S)).tolist():
     eng.add_prompt(p, sp)
-while eng.scheduler.waiting:
+while eng.scheduler.waiting or eng.model_runner.has_prefill_ahead():
     eng.step()
 for _ in range(4):
     eng.step()
