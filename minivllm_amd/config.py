@@ -220,6 +220,13 @@ class EngineConfig:
     # post-processes; single-rank engines with graph-replayed decode steps only
     # (ModelRunner._can_prelaunch; MINIVLLM_NO_PRELAUNCH=1 switches it off)
     decode_prelaunch: bool = True
+    # ... also across KV-block edges (a sequence whose next token starts a new block is given
+    # that block when the step is launched ahead, and a block the step completes has its hash
+    # published when the step is collected) and while requests wait that cannot be admitted
+    # (every slot taken, blocks short, a small prefill step held back).  Off: only steps that
+    # touch no block edge, and only while nobody waits - with mixed context lengths or a
+    # saturated engine that is a minority of the steps
+    decode_prelaunch_edges: bool = True
     # consecutive pure prefill steps: admit, prepare and (when the step's graph exists) enqueue
     # step n + 1 before reading step n's tokens back (Scheduler.schedule_prefill_ahead,
     # ModelRunner.run(next_prefill=...)); MINIVLLM_NO_PRELAUNCH=1 switches it off as well

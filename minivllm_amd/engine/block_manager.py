@@ -184,6 +184,13 @@ class BlockManager:
                     last.update(h, token_ids)
                     self.hash_to_block_id[h] = last.block_id
 
+    def append_ahead(self, seq: Sequence) -> None:
+        """Give ``seq`` the block that the token AFTER its newest one starts, if it has none yet
+        (for a decode step launched before the current step's token is known; the caller has
+        checked ``num_free_blocks``)."""
+        if len(seq.block_table) * self.block_size < seq.num_tokens + 1:
+            seq.block_table.append(self._fresh_block().block_id)
+
     # ------------------------------------------------------------------ stats
     def stats(self) -> dict:
         return {
@@ -331,6 +338,16 @@ class NativeBlockManager:
         if added >= 0:
             bt.append(added)
         assert len(bt) == seq.num_blocks
+
+    def append_ahead(self, seq: Sequence) -> None:
+        """See :meth:`BlockManager.append_ahead`."""
+        bt = seq.block_table
+        added = self._lib.mvl_bm_append(self._h, len(bt), bt[-1] if bt else -1,
+                                        bt[-2] if len(bt) > 1 else -1, seq.num_tokens + 1, None)
+        if added == -2:
+            raise RuntimeError("append_ahead() without a free block (check num_free_blocks first)")
+        if added >= 0:
+            bt.append(added)
 
     @property
     def num_prefix_hits(self) -> int:

@@ -93,7 +93,9 @@ class LLMEngine:
                                    enable_chunked_prefill=cfg.enable_chunked_prefill,
                                    min_prefill_tokens=cfg.min_prefill_tokens,
                                    max_prefill_delay_s=cfg.max_prefill_delay_ms / 1e3,
-                                   enable_mixed_batches=cfg.enable_mixed_batches)
+                                   enable_mixed_batches=cfg.enable_mixed_batches,
+                                   ahead_over_block_edges=(cfg.decode_prelaunch_edges and os.environ.get(
+                                       "MINIVLLM_NO_EDGE_PRELAUNCH") != "1"))
         self.tokenizer = load_tokenizer(cfg.model_name_or_path, cfg.model.vocab_size)
         self.stats = EngineStats()
         self._exited = False
@@ -187,8 +189,8 @@ class LLMEngine:
             else:
                 self._check_workers()
                 seqs = [ahead[i] for i in alive]
-                self.scheduler.consume_plain_decode_step()
-                again = len(alive) == len(ahead) and self.scheduler.next_decode_step_is_plain()
+                self.scheduler.consume_decode_step_ahead(seqs)
+                again = self.scheduler.next_decode_step_ahead() if len(alive) == len(ahead) else 0
                 self._step_seq += 1
                 self._in_step = self._step_seq
                 try:
@@ -235,7 +237,7 @@ class LLMEngine:
         self._step_seq += 1
         self._in_step = self._step_seq
         try:
-            ahead_ok = not is_prefill and self.scheduler.next_decode_step_is_plain()
+            ahead_ok = 0 if is_prefill else self.scheduler.next_decode_step_ahead()
             token_ids = self.model_runner.run(seqs, is_prefill, riders, allow_prelaunch=ahead_ok,
                                               next_prefill=ahead_fn if is_prefill and not riders else None)
         finally:

@@ -475,7 +475,8 @@ class ModelRunner:
                         self.execute(b)
             elif method == "prelaunch_next":     # rank 0 keeps launching ahead: one more step
                 with torch.inference_mode():
-                    self._prelaunch_after(None, self._spec["batch"], self._spec["tokens"])
+                    self._prelaunch_after(None, self._spec["batch"], self._spec["tokens"],
+                                          (arrays or {}).get("block_tables"))
                 if self._spec["batch"].step % self.P2P_CHECK_EVERY == 0:
                     pg.check_custom_all_reduce(synchronize=True)
             elif method == "exit":
@@ -745,10 +746,11 @@ class ModelRunner:
             allow_prelaunch: bool = False, next_prefill=None) -> Optional[List[int]]:
         """Rank 0 entry point for one step; returns the sampled token per sequence.
         ``num_decode`` > 0 (prefill steps only): the last that many sequences decode.
-        ``allow_prelaunch`` (decode steps): the caller guarantees that the NEXT step is a plain
-        decode step of the same sequences (nobody crosses a KV-block edge, nothing waits to be
-        admitted), so that step may be launched before this one's tokens are read back; the
-        caller then collects it with ``run_prelaunched``.
+        ``allow_prelaunch`` (decode steps; ``Scheduler.next_decode_step_ahead``): non-zero when the
+        caller guarantees that the NEXT step is a decode step of the same sequences (nothing
+        waits to be admitted; 2 = some of them have just been given a new KV block for it), so
+        that step may be launched before this one's tokens are read back; the caller then
+        collects it with ``run_prelaunched``.
         ``next_prefill`` (pure prefill steps): a callable that admits and returns the sequences
         of the prefill step after this one, or [] (``Scheduler.schedule_prefill_ahead``); that
         step is then prepared, and where possible launched, before this one's tokens are read
@@ -761,7 +763,12 @@ class ModelRunner:
             batch = self.prepare_decode(seqs)
         self.step_counter += 1
         batch.step = self.step_counter
-        batch.prelaunch = allow_prelaunch and self._can_prelaunch(batch)
+        batch.prelaunch = bool(allow_prelaunch) and self._can_prelaunch(batch)
+        if not is_prefill and allow_prelaunch == 2:
+            # the scheduler has just given some sequences the block their token after this one
+            # starts: the tables every rank derives the next step from must hold it
+            batch.arrays["block_tables"] = _pad_block_tables([s.block_table for s in seqs])
+            batch.tables_unchanged = False
         if is_prefill and next_prefill is not None and num_decode == 0:
             return self._run_prefill_with_lookahead(batch, next_prefill, self._PG_KEY_UNSET)
         if self.world_size > 1 and self.rank == 0:
@@ -933,20 +940,23 @@ class ModelRunner:
             pg.check_custom_all_reduce(synchronize=False)
         return host.tolist()
 
-    def _prelaunch_after(self, seqs, b: Batch, tokens_dev: torch.Tensor) -> None:
-        """Enqueue the decode step that follows ``b`` for the same sequences."""
+    def _prelaunch_after(self, seqs, b: Batch, tokens_dev: torch.Tensor, tables=None) -> None:
+        """Enqueue the decode step that follows ``b`` for the same sequences.  ``tables``: the
+        sequences' block tables if they have grown since ``b`` was made."""
         a, bs = b.arrays, self.block_size
         B = b.num_seqs
         lens = a["context_lens"] + 1
         pos = lens - 1
-        tables = a["block_tables"]
+        grown = tables is not None
+        if not grown:
+            tables = a["block_tables"]
         blk = tables[self._arange(B), pos // bs]
         arrays = dict(input_ids=np.zeros(B, np.int32),         # replaced on the device
                       positions=pos, slot_mapping=blk * bs + pos % bs, context_lens=lens,
                       temperatures=a["temperatures"], block_tables=tables)
         m = int(lens.max())
         nxt = Batch(is_prefill=False, num_seqs=B, num_tokens=B, max_seqlen_q=1, max_seqlen_k=m,
-                    max_context_len=m, arrays=arrays, tables_unchanged=True)
+                    max_context_len=m, arrays=arrays, tables_unchanged=not grown)
         nxt.step = self.step_counter = b.step + 1        # workers take the count from the batch
         out_dev = self._launch_decode(nxt, input_ids_dev=tokens_dev)
         self._spec = dict(seqs=seqs, batch=nxt, tokens=out_dev)
@@ -965,7 +975,7 @@ class ModelRunner:
         self._decode_prev = None
         self._last_tokens = None
 
-    def run_prelaunched(self, alive: Seq[int], allow_prelaunch: bool = False) -> List[int]:
+    def run_prelaunched(self, alive: Seq[int], allow_prelaunch: int = 0) -> List[int]:
         """Collect the step launched ahead: the tokens of the rows ``alive`` (indices into
         ``prelaunched_seqs()``; the other sequences finished in the meantime).  With every
         row alive and ``allow_prelaunch`` the step after it is launched ahead in turn."""
@@ -974,9 +984,12 @@ class ModelRunner:
         with torch.inference_mode(), trace_range("decode_step"):
             pending = self._read_tokens_async(spec["tokens"], b.num_seqs)
             if allow_prelaunch and len(alive) == b.num_seqs and self._can_prelaunch(b):
+                tables = (_pad_block_tables([s.block_table for s in seqs])
+                          if allow_prelaunch == 2 else None)
                 if self.world_size > 1:
-                    self.channel.send("prelaunch_next", {})
-                self._prelaunch_after(seqs, b, spec["tokens"])
+                    self.channel.send("prelaunch_next", {},
+                                      {} if tables is None else {"block_tables": tables})
+                self._prelaunch_after(seqs, b, spec["tokens"], tables)
             out = self._finish_read(pending)
         # a normal step for the same list continues from here (prepare_decode's shortcut)
         b.arrays["input_ids"] = np.asarray(out, dtype=np.int32)

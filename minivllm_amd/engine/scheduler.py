@@ -38,8 +38,13 @@ class Scheduler:
                  max_cached_blocks: int, block_size: int, eos: int,
                  max_model_length: Optional[int] = None, enable_chunked_prefill: bool = True,
                  min_prefill_tokens: int = 0, max_prefill_delay_s: float = 0.0,
-                 enable_mixed_batches: bool = False):
+                 enable_mixed_batches: bool = False, ahead_over_block_edges: bool = True):
         self.enable_chunked_prefill = enable_chunked_prefill
+        # decode steps launched ahead may cross KV-block edges (blocks allocated ahead, block
+        # hashes published when the step is collected) and go on while requests wait that cannot
+        # be admitted; off: only steps that touch no edge, and only while nobody waits
+        self.ahead_over_block_edges = ahead_over_block_edges
+        self._edge_ahead = False
         # > 0: while sequences are decoding, newcomers are admitted only once this many prompt
         # tokens can go into one prefill step (or everything that waits fits).  The reference
         # interrupts the decode batch for every single newcomer (scheduler.py:29-41), which
@@ -146,19 +151,11 @@ class Scheduler:
             num_tokens += 1
         self.running.extend(scheduled)
         self.running.extend(deferred)
-        if scheduled and not deferred and not self.waiting:
-            # after this step a sequence holds n + 1 tokens; the step scheduled for length m
-            # is plain unless m % bs is 0 (publishes a hash) or 1 (needs a new block)
-            plain, wanted = bs, 0
-            for seq in scheduled:
-                r = (seq.num_tokens + 1) % bs
-                plain = min(plain, 0 if r <= 1 else bs - r)
-                # steps after this one in which the sequence still wants a token
-                wanted = max(wanted, seq.max_tokens - seq.num_completion_tokens - 1)
-            # once every sequence has reached its max_tokens there is no next step: a step
-            # launched ahead of that point would run (and be drained) for nothing
-            plain = min(plain, wanted)
-            self._decode_batch, self._plain_decode_steps = scheduled, (plain if bs > 2 else 0)
+        self._edge_ahead = False
+        if scheduled and not deferred:
+            # (somebody may be waiting: then admission was not possible just now, and the step
+            # after this one can still be launched ahead while that stays so)
+            self._decode_batch, self._plain_decode_steps = scheduled, self._count_plain_steps(scheduled)
         else:
             self._decode_batch = None
         return scheduled, False
@@ -243,17 +240,78 @@ class Scheduler:
         return scheduled
 
     # ------------------------------------------------ decode steps launched ahead
+    def _count_plain_steps(self, batch: List[Sequence]) -> int:
+        """How many decode steps AFTER the one that processes the sequences' current lengths
+        touch no block edge and still have somebody who wants a token."""
+        bs = self.block_size
+        # after that step a sequence holds n + 1 tokens; the step scheduled for length m is
+        # plain unless m % bs is 0 (publishes a hash) or 1 (needs a new block)
+        plain, wanted = bs, bs
+        for seq in batch:
+            r = (seq.num_tokens + 1) % bs
+            plain = min(plain, 0 if r <= 1 else bs - r)
+            # steps after that one in which the sequence still wants a token
+            wanted = min(wanted, seq.max_tokens - seq.num_completion_tokens - 1)
+        # no step is launched ahead of the point where a sequence reaches its max_tokens: the
+        # batch that follows is a different one (its rows renumbered, which the sampler's noise
+        # is keyed by), and a row launched for a sequence that is done would run for nothing
+        return max(min(plain, wanted), 0) if bs > 2 else 0
+
+    def next_decode_step_ahead(self) -> int:
+        """After a decode step has been scheduled (or while one launched ahead is in flight):
+        may the step after it be launched before its tokens are known?  0: no - someone waits
+        who could be admitted (a free slot, enough blocks, no hold-back), the batch is not
+        everybody, blocks are short, or a sequence reaches its ``max_tokens``.  1: yes, the same batch with the same block tables.  2: yes, and sequences whose
+        next token starts a new KV block have just been given that block (their tables grew).
+        A block that the step will complete has its hash published when the step is collected
+        (``consume_decode_step_ahead``): that needs the token sampled in between."""
+        if self._decode_batch is None or self.prefilling or self._admission_possible():
+            return 0
+        if self._plain_decode_steps > 0:
+            return 1
+        bs, bm, batch = self.block_size, self.block_manager, self._decode_batch
+        if not self.ahead_over_block_edges or bs <= 2 or not batch:
+            return 0
+        if min(s.max_tokens - s.num_completion_tokens - 1 for s in batch) <= 0:
+            return 0                                    # somebody finishes: the batch changes
+        need = [s for s in batch if len(s.block_table) * bs < s.num_tokens + 1]
+        if bm.num_free_blocks < len(need):
+            return 0                                    # schedule() decides whom to preempt
+        for s in need:
+            bm.append_ahead(s)
+        self._edge_ahead = True
+        return 2 if need else 1
+
+    def _admission_possible(self) -> bool:
+        """Would ``schedule`` start a prefill step for the oldest waiting request right now?
+        (While every slot is taken, the pool cannot hold the request or a small prefill step is
+        being held back, a saturated engine keeps decoding the same batch.)"""
+        if not self.ahead_over_block_edges:
+            return bool(self.waiting)                   # the cautious rule: nobody may wait
+        if not self.waiting or self._defer_prefill():
+            return False
+        return (self.block_manager.can_allocate(self.waiting[0])
+                and len(self.running) < self.max_num_sequences)
+
     def next_decode_step_is_plain(self) -> bool:
-        """After a decode step has been scheduled: will the step after it be the same batch
-        again with nothing to allocate, publish or admit (so that the runner may launch it
-        before this one's tokens are known)?"""
+        """The step after the scheduled one is the same batch with nothing to allocate or
+        publish."""
         return (self._decode_batch is not None and self._plain_decode_steps > 0
                 and not self.waiting and not self.prefilling)
 
-    def consume_plain_decode_step(self) -> None:
-        """Account for a step that ran without ``schedule()`` having been asked (it had been
-        launched ahead): one plain step of the current batch is used up."""
-        if self._decode_batch is not None and self._plain_decode_steps > 0:
+    def consume_decode_step_ahead(self, seqs: List[Sequence]) -> None:
+        """Account for a decode step that ran without ``schedule()`` having been asked (it had
+        been launched ahead) and is now being collected for ``seqs``: publish the blocks it
+        completes, use up one plain step or count the plain steps that follow an edge."""
+        if self._edge_ahead:
+            self._edge_ahead = False
+            bm, bs = self.block_manager, self.block_size
+            for s in seqs:
+                if s.num_tokens % bs == 0:
+                    bm.append(s)
+            if self._decode_batch is not None:
+                self._plain_decode_steps = self._count_plain_steps(self._decode_batch)
+        elif self._decode_batch is not None and self._plain_decode_steps > 0:
             self._plain_decode_steps -= 1
 
     def _add_decode_riders(self, scheduled: List[Sequence], num_tokens: int) -> None:

@@ -58,10 +58,11 @@ def _validate_every_staging_block(monkeypatch):
     monkeypatch.setattr(mr, "_CHECK_BATCHES", True)
 
 
-def _run(ahead, stop=(), abort_at=None, lens=(5, 40, 17, 33, 40, 9, 28, 40), buckets=(1, 2, 4, 8)):
+def _run(ahead, stop=(), abort_at=None, lens=(5, 40, 17, 33, 40, 9, 28, 40), buckets=(1, 2, 4, 8),
+         info=None, **kw):
     rng = np.random.default_rng(9)
     prompts = [rng.integers(0, 300, size=int(rng.integers(5, 60))).tolist() for _ in lens]
-    eng = _engine(buckets=buckets, decode_prelaunch=ahead)
+    eng = _engine(buckets=buckets, decode_prelaunch=ahead, **kw)
     seqs = [eng.add_prompt(p, SamplingParams(temperature=0, max_tokens=n, ignore_eos=True,
                                              stop_token_ids=list(stop)))
             for p, n in zip(prompts, lens)]
@@ -70,12 +71,17 @@ def _run(ahead, stop=(), abort_at=None, lens=(5, 40, 17, 33, 40, 9, 28, 40), buc
         finished, _, _ = eng.step()
         done.update(finished)
         launched += eng.model_runner.has_prelaunched()
+        if info is not None and eng.model_runner.has_prelaunched():
+            info["edges"] = info.get("edges", 0) + (not eng.model_runner._spec["batch"].tables_unchanged)
         steps += 1
         if steps == abort_at:
             assert eng.scheduler.abort(seqs[4])
         assert steps < 500
     bm = eng.scheduler.block_manager
     assert bm.num_free_blocks == bm.num_blocks
+    if info is not None:
+        info.update(decode_steps=steps, hashes=bm.stats()["cached_hashes"],
+                    preemptions=eng.scheduler.num_preemptions)
     eng.exit()
     return [done.get(s.seq_id) for s in seqs], launched
 
@@ -116,3 +122,48 @@ def test_late_arrivals_wait_for_the_step_in_flight_and_then_join():
         return [done[s.seq_id] for s in seqs]
 
     assert go(True) == go(False)
+
+
+def test_steps_across_block_edges_are_launched_ahead_too():
+    """Block size 8, eight sequences of different lengths: nearly every decode step starts a
+    new KV block or completes one for somebody.  Those steps are launched ahead as well (blocks
+    given ahead, hashes published when the step is collected), the tokens and the set of
+    published block hashes are those of the plain loop."""
+    plain_i, edges_i, no_edges_i = {}, {}, {}
+    plain, _ = _run(False, info=plain_i)
+    ahead, n_ahead = _run(True, info=edges_i)
+    old, n_old = _run(True, info=no_edges_i, decode_prelaunch_edges=False)
+    assert ahead == plain == old
+    assert edges_i["edges"] >= 6                        # steps whose tables grew, launched ahead
+    assert no_edges_i.get("edges", 0) == 0
+    # all steps but the prefill step and the one after each sequence's (foreseen) finish
+    assert n_ahead > 2 * n_old and n_ahead >= edges_i["decode_steps"] - 10
+    assert edges_i["hashes"] == plain_i["hashes"] == no_edges_i["hashes"] > 0
+
+
+def test_launch_ahead_steps_aside_when_blocks_run_out():
+    """A cache too small for everybody: a step that would need more blocks than are free is not
+    launched ahead (the scheduler preempts as usual), and the outcome is the plain loop's."""
+    lens = (40, 40, 40, 40, 40, 40)
+    plain_i, ahead_i = {}, {}
+    plain, _ = _run(False, lens=lens, info=plain_i, max_cached_blocks=40)
+    ahead, n = _run(True, lens=lens, info=ahead_i, max_cached_blocks=40)
+    assert plain_i["preemptions"] > 0 and ahead_i["preemptions"] > 0
+    assert n > 5 and ahead == plain
+
+
+def test_a_saturated_engine_keeps_launching_ahead_while_nobody_can_be_admitted():
+    """More requests than sequence slots: while every slot is taken the waiting requests
+    cannot be admitted, so the decode batch stays the same and its steps are launched ahead;
+    the step after a sequence's last token is scheduled normally and admits the next request,
+    exactly when the plain loop does."""
+    lens = (9, 30, 14, 22, 30, 11, 26, 30, 7, 19, 30, 12, 25, 16, 30, 8)
+    kw = dict(lens=lens, buckets=(1, 2, 4), max_num_sequences=4)
+    plain_i, ahead_i = {}, {}
+    plain, n0 = _run(False, info=plain_i, **kw)
+    ahead, n1 = _run(True, info=ahead_i, **kw)
+    assert n0 == 0 and ahead == plain and all(o is not None for o in ahead)
+    assert ahead_i["decode_steps"] == plain_i["decode_steps"]          # same steps, same order
+    # every step but the prefill steps and the first decode step after each admission
+    assert n1 >= ahead_i["decode_steps"] - 3 * len(lens)
+    assert n1 > 0.5 * ahead_i["decode_steps"]
