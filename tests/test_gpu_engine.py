@@ -298,7 +298,7 @@ def test_single_sequence_prefill_graphs_match_eager_prefill(gpu):
 def test_serving_loop_in_a_thread_with_graphs_matches_offline(gpu):
     """The online engine loop builds the engine, captures its hipGraphs and steps it in a
     background thread; requests that trickle in must produce the tokens of an offline run
-    (sampling noise is keyed by sequence and step, not by batch composition)."""
+    (greedy requests: the tokens do not depend on how the requests were batched)."""
     import time
     from minivllm_amd.engine.llm_engine import LLMEngine
     from minivllm_amd.serve import AsyncLLMEngine
