@@ -743,7 +743,7 @@ class ModelRunner:
 
     # ================================================================== run
     def run(self, seqs: Seq[Sequence], is_prefill: bool, num_decode: int = 0,
-            allow_prelaunch: bool = False, next_prefill=None) -> Optional[List[int]]:
+            allow_prelaunch: int = 0, next_prefill=None) -> Optional[List[int]]:
         """Rank 0 entry point for one step; returns the sampled token per sequence.
         ``num_decode`` > 0 (prefill steps only): the last that many sequences decode.
         ``allow_prelaunch`` (decode steps; ``Scheduler.next_decode_step_ahead``): non-zero when the
@@ -788,7 +788,8 @@ class ModelRunner:
     # retires the sequences, admits the next ones, builds their batch arrays and replays the
     # graph (~0.4 ms: 2.5 % of a 16k-token Qwen3-0.6B step, more of the 1-4 ms steps a server
     # sees).  None of that needs the running step's samples when the next step is made of
-    # sequences that are still waiting: they are admitted while the step runs
+    # sequences that are still waiting (or continues a prompt the running step has cut at its
+    # token budget): they are admitted while the step runs
     # (``Scheduler.schedule_prefill_ahead``), their inputs go up behind it (second pinned
     # staging block; the device-side input buffer is only written in stream order, after the
     # running graph has read it) and their graph is replayed behind that; only then does the

@@ -8,6 +8,9 @@ from minivllm_amd.engine.llm_engine import LLMEngine
 from minivllm_amd.sampling_parameters import SamplingParams
 
 model = sys.argv[1] if len(sys.argv) > 1 else "qwen3-0.6b"
+# "churn": every step goes the long way (full scheduling loop, batch arrays rebuilt from the
+# sequences), as when the batch changes from step to step; default: the steady-state shortcuts
+CHURN = len(sys.argv) > 2 and sys.argv[2] == "churn"
 B, S, K = 256, 1024, 40
 cfg = EngineConfig(model=model_preset(model), max_num_sequences=B, max_num_batched_tokens=16384,
                    block_size=256, eos=-1, max_model_length=2048, gpu_memory_utilization=0.85,
@@ -26,6 +29,8 @@ r = eng.model_runner
 torch.cuda.synchronize()
 t_all = time.perf_counter()
 for _ in range(K):
+    if CHURN:
+        eng.scheduler._decode_batch, r._decode_prev = None, None
     t0 = time.perf_counter()
     seqs, is_prefill = eng.scheduler.schedule()
     t1 = time.perf_counter()
@@ -46,5 +51,5 @@ for _ in range(K):
     for k, v in zip(T, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
         T[k] += v
 tot = time.perf_counter() - t_all
-print(f"{model}: {tot / K * 1e3:.3f} ms/step;", {k: f"{v / K * 1e6:.0f} us" for k, v in T.items()})
+print(f"{model}{' (churn)' if CHURN else ''}: {tot / K * 1e3:.3f} ms/step;", {k: f"{v / K * 1e6:.0f} us" for k, v in T.items()})
 eng.exit()
