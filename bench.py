@@ -206,14 +206,25 @@ def bench_model(args, model_name: str, rank: int, world: int, replicas: bool = F
     if args.mode in ("both", "prefill"):
         per_step = max(1, min(args.prefill_tokens // S, B))
         sp = SamplingParams(temperature=0.6, max_tokens=1, ignore_eos=True)
-        # one step more than is timed: consecutive prefill steps are launched one ahead, so a step
-        # is in flight when the window opens (timer_start drains it) and the last timed call
-        # launches one that timer_stop drains: the window holds exactly K steps of GPU work
-        for p in prompts(per_step * (W + K + 1), S):
+        # Consecutive prefill steps are launched one ahead: a step is in flight when the window
+        # opens (timer_start drains it) and the last timed call launches one more, which timer_stop
+        # drains, so the window holds exactly K steps of GPU work.  The look-ahead starts with the
+        # step after the one that captures the shape's graph: if the warm-up was too short for
+        # that (W = 1), up to two more untimed steps bring the pipeline into its steady state -
+        # a window that opens with nothing in flight but closes on a launched-ahead step would
+        # hold K + 1 steps of work.
+        extra = 2
+        for p in prompts(per_step * (W + extra + K + 1), S):
             eng.add_prompt(p, sp)
         for _ in range(W):
             _, n, is_prefill = eng.step()
             assert is_prefill
+        mr = eng.model_runner
+        while extra and cfg.prefill_prelaunch and not mr.prefill_ahead_in_flight():
+            _, n, is_prefill = eng.step()
+            assert is_prefill
+            extra -= 1
+        res["prefill_steps_launched_ahead"] = mr.prefill_ahead_in_flight()
         runner.call("timer_start")
         tokens = 0
         for _ in range(K):

@@ -852,6 +852,10 @@ class ModelRunner:
     def has_prefill_ahead(self) -> bool:
         return self._pf_spec is not None
 
+    def prefill_ahead_in_flight(self) -> bool:
+        """The step admitted ahead is already on the device (its graph existed)."""
+        return self._pf_spec is not None and self._pf_spec["pending"] is not None
+
     def prefill_ahead_info(self):
         """(sequences, prompt tokens computed) of the prefill step admitted ahead."""
         return self._pf_spec["seqs"], self._pf_spec["num_tokens"]
