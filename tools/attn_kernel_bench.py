@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--q-rope", action="store_true",
                     help="prefill: q-norm + RoPE of the Q rows inside the kernel (the engine's pure "
                          "prefill steps)")
+    ap.add_argument("--splits", type=int, default=0, help="decode: context splits (0 = the library's rule)")
     ap.add_argument("--fused-store", action="store_true",
                     help="decode: the engine's form (raw q / k / v of the new token in; the kernel "
                          "norms, rotates and stores them itself)")
@@ -100,7 +101,8 @@ def main():
                 w = lambda: torch.rand(d, device="cuda", dtype=torch.bfloat16) + 0.5
                 new_kv = (qkv[:, hq * d:(hq + hkv) * d].view(B, hkv, d), qkv[:, (hq + hkv) * d:].view(B, hkv, d),
                           torch.cat([ang.cos(), ang.sin()], 1).contiguous(), w(), w(), 1e-6)
-            t = timeit(lambda: hip.paged_attention_decode(q, kc, vc, bt, ctx, scale, S, new_kv=new_kv), a.iters)
+            t = timeit(lambda: hip.paged_attention_decode(q, kc, vc, bt, ctx, scale, S, new_kv=new_kv,
+                                                          num_splits=a.splits or None), a.iters)
             by = 2 * B * S * hkv * d * eb
             print(f"decode  B={B} ctx={S}: {t*1e3:8.3f} ms  {by/t/1e12:6.2f} TB/s KV stream", flush=True)
             del kc, vc, q
