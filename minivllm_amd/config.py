@@ -225,7 +225,7 @@ class EngineConfig:
     # published when the step is collected) and while requests wait that cannot be admitted
     # (every slot taken, blocks short, a small prefill step held back).  Off: only steps that
     # touch no block edge, and only while nobody waits - with mixed context lengths or a
-    # saturated engine that is a minority of the steps
+    # saturated engine that is a minority of the steps (MINIVLLM_NO_EDGE_PRELAUNCH=1: off, for A/B runs)
     decode_prelaunch_edges: bool = True
     # consecutive pure prefill steps: admit, prepare and (when the step's graph exists) enqueue
     # step n + 1 before reading step n's tokens back (Scheduler.schedule_prefill_ahead,
