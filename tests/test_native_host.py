@@ -48,6 +48,7 @@ def test_same_decisions_as_python_on_a_random_workload():
     py, cc = BlockManager(48, BS), NativeBlockManager(48, BS)
     prefixes = [rng.integers(0, 50, size=int(n)).tolist() for n in (8, 12, 4, 16)]
     live = []                                             # pairs (python seq, native seq)
+    ahead = 0
     for step in range(3000):
         op = rng.integers(0, 10)
         if op < 3:                                        # admit a prompt, often with a shared prefix
@@ -65,6 +66,11 @@ def test_same_decisions_as_python_on_a_random_workload():
             assert py.can_append(a) == cc.can_append(b)
             if py.can_append(a):
                 py.append(a), cc.append(b)
+                # now and then the step after this one is launched ahead: the block its token
+                # starts is given out before that token exists
+                if rng.random() < 0.3 and py.num_free_blocks >= 1:
+                    py.append_ahead(a), cc.append_ahead(b)
+                    ahead += len(a.block_table) > a.num_blocks
             else:                                         # preempt: free and forget
                 py.deallocate(a), cc.deallocate(b)
                 live.remove((a, b))
@@ -78,6 +84,7 @@ def test_same_decisions_as_python_on_a_random_workload():
     assert (ps["free"], ps["used"], ps["cached_hashes"]) == (cs["free"], cs["used"], cs["cached_hashes"])
     assert (py.num_prefix_hits, py.num_prefix_queries) == (cc.num_prefix_hits, cc.num_prefix_queries)
     assert py.num_prefix_hits > 50                        # the workload did exercise sharing
+    assert ahead > 20                                     # ... and blocks given out ahead
     for a, b in live:
         assert all(py.blocks[i].ref_count == cc.ref_count(i) for i in a.block_table)
 
